@@ -1,0 +1,1500 @@
+// fisher_rast.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of
+// libfisher_rast.so.  See include/fisher_rast.h for the boundary and DESIGN.md for the layout.
+//
+// Pipeline (single view: V = 1; Fisher scorer: V candidate views batched as blockIdx.y):
+//   k_cov3d            once per call      scale/quaternion -> cov3D[P][6]            (forward.cu:118-152)
+//   k_preprocess       grid (P/1024, V)   project, cull, conic, radius, tile rect, per-tile COUNT
+//                                         through an LDS histogram                   (forward.cu:155-256)
+//   k_scan_tiles       1 block            exclusive scan of the V*T tile counts -> segment offsets,
+//                                         device-side num_rendered / overflow flag   (replaces cub::InclusiveSum +
+//                                         the blocking cudaMemcpy of rasterizer_impl.cu:277-282)
+//   k_scatter_keys     grid (P/1024, V)   emit (depth_bits<<32 | gaussian) into the tile's segment
+//                                         (duplicateWithKeys, rasterizer_impl.cu:70-111)
+//   k_sort_tiles       grid (T, V)        per-tile bitonic network in LDS on the 64-bit keys: replaces the global
+//                                         cub::DeviceRadixSort (rasterizer_impl.cu:304-309).  Keys are unique, so the
+//                                         result equals the reference's stable (tile, depth) order with ties by index.
+//   k_render_forward   grid (T, V)        alpha compositing, median depth           (forward.cu:261-393)
+//   k_backward_tile    grid (T, 1)        fused backward with grad_power            (backward.cu:850-1140)
+//   k_fisher_tile      grid (T, V)        transmittance pass + backward(power=2) + sum(cur_H * H_inv) fused:
+//                                         gaussian.py:1548-1556,1367 without materialising any gradient tensor
+//
+// Wave64 mapping of a 16x16 tile: 256 threads = 4 waves, wave w owns the 16x4 pixel strip of rows 4w..4w+3, so a
+// small splat is seen by 1-2 waves and the others skip it with one ballot.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "fr_math.h"
+#include "../../include/fisher_rast.h"
+
+#define FR_THREADS 256
+#define FR_G_PER_THREAD 4            // Gaussians per thread in the per-Gaussian kernels
+#define FR_MAX_LDS_TILES 4096        // tile histogram kept in LDS up to 1024x1024 images
+#define FR_SORT_LDS_KEYS 4096        // per-tile segments up to this size are sorted in LDS (32 KiB)
+#define FR_BATCH 256                 // splats staged per round in the forward pass
+#define FR_BWD_BATCH 128             // splats staged per round in the backward passes
+
+static thread_local char g_err[512] = "";
+static int fr_fail(int code, const char* msg)
+{
+	snprintf(g_err, sizeof(g_err), "%s", msg);
+	return code;
+}
+static int fr_check_launch(const char* what)
+{
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+	{
+		snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+		return FR_ELAUNCH;
+	}
+	return FR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct FrParams {
+	int P, V, W, H;
+	uint32_t gx, gy;
+	int T;                       // tiles per view
+	float tanfovx, tanfovy, focal_x, focal_y, mod;
+	int D, M;
+	const float* bg; const float* view; const float* proj; const float* campos;
+	const float* w2c;            // [V][16] row-major, or null
+	const float* means3D; const float* colors; const float* shs; const float* opac;
+	const float* scales; const float* rots;
+	const float* cov3D;          // [P][6] (precomputed input or output of k_cov3d)
+	float* cov3D_out;
+	int* radii;                  // [V][P]
+	float* depths;               // [V][P]
+	fr_f2* means2D;              // [V][P]
+	fr_f4* conic_op;             // [V][P]
+	float* rgb;                  // [V][P][3]  (SH path only)
+	uint8_t* clamped;            // [V][P][3]
+	uint32_t* tile_cnt; uint32_t* tile_off; uint32_t* tile_fill; // [V][T]
+	uint64_t* keys; long long key_capacity;
+	int* status;                 // [4]
+	int* vis_count;              // [V] or null
+	int* num_rendered;           // [V] or null
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+	return v;
+}
+
+// conservative lower bound on `power` below which alpha = opacity*exp(power) is certainly < 1/255
+__device__ __forceinline__ float fr_power_threshold(float opacity)
+{
+	return (opacity > 0.f) ? (-__logf(255.0f * opacity) - 0.01f) : INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FR_THREADS) void k_cov3d(int P, const float* __restrict__ scales, float mod,
+                                                      const float* __restrict__ rots, float* __restrict__ cov3D)
+{
+	int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= P) return;
+	fr_f3 s = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
+	fr_f4 q = { rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3] };
+	float c[6];
+	fr_cov3d(s, mod, q, c);
+#pragma unroll
+	for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = c[k];
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                             const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+	int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= P) return;
+	float vm[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) vm[k] = view[k];
+	fr_f3 p = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+	fr_f3 pv = fr_xform4x3(p, vm);
+	present[i] = (pv.z <= 0.001f) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
+{
+	__shared__ uint32_t hist[FR_MAX_LDS_TILES];
+	const int tid = threadIdx.x;
+	const int v = blockIdx.y;
+	const bool lds_hist = p.T <= FR_MAX_LDS_TILES;
+	if (lds_hist)
+	{
+		for (int t = tid; t < p.T; t += FR_THREADS) hist[t] = 0;
+		__syncthreads();
+	}
+	float vm[16], pm[16], wm[12];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const bool has_w2c = p.w2c != nullptr;
+	if (has_w2c)
+	{
+#pragma unroll
+		for (int k = 0; k < 12; k++) wm[k] = p.w2c[16 * (size_t)v + k];
+	}
+	uint32_t* cnt = p.tile_cnt + (size_t)v * p.T;
+	const size_t vP = (size_t)v * p.P;
+	int nvis = 0;
+	for (int g = 0; g < FR_G_PER_THREAD; g++)
+	{
+		const int i = (blockIdx.x * FR_G_PER_THREAD + g) * FR_THREADS + tid;
+		if (i >= p.P) break;
+		fr_f3 pw = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+		fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+		// cheap reject first (identical to the first test of preprocess_one) so culled splats never load cov3D
+		fr_f3 p_view = fr_xform4x3(po, vm);
+		fr_splat s;
+		s.radius = 0;
+		if (!(p_view.z <= 0.001f))
+		{
+			float c3[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
+			s = fr_preprocess_one(po, c3, vm, pm, p.W, p.H, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.gx, p.gy);
+		}
+		p.radii[vP + i] = s.radius;
+		if (s.radius > 0)
+		{
+			nvis++;
+			p.depths[vP + i] = s.depth;
+			fr_f2 xy = { s.px, s.py };
+			p.means2D[vP + i] = xy;
+			fr_f4 co = { s.conx, s.cony, s.conz, p.opac[i] };
+			p.conic_op[vP + i] = co;
+			if (p.colors == nullptr)
+			{
+				fr_f3 cp = { p.campos[0], p.campos[1], p.campos[2] };
+				uint8_t cl[3];
+				fr_f3 c = fr_sh_to_rgb(p.D, po, cp, p.shs + 3 * (size_t)i * p.M, cl);
+				p.rgb[3 * (vP + i)] = c.x; p.rgb[3 * (vP + i) + 1] = c.y; p.rgb[3 * (vP + i) + 2] = c.z;
+				p.clamped[3 * (vP + i)] = cl[0]; p.clamped[3 * (vP + i) + 1] = cl[1]; p.clamped[3 * (vP + i) + 2] = cl[2];
+			}
+			for (uint32_t y = s.rect.y0; y < s.rect.y1; y++)
+				for (uint32_t x = s.rect.x0; x < s.rect.x1; x++)
+				{
+					if (lds_hist) atomicAdd(&hist[y * p.gx + x], 1u);
+					else atomicAdd(&cnt[y * p.gx + x], 1u);
+				}
+		}
+	}
+	if (lds_hist)
+	{
+		__syncthreads();
+		for (int t = tid; t < p.T; t += FR_THREADS)
+		{
+			uint32_t c = hist[t];
+			if (c) atomicAdd(&cnt[t], c);
+		}
+	}
+	if (p.vis_count)
+	{
+		int s = nvis;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+		if ((tid & 63) == 0 && s) atomicAdd(&p.vis_count[v], s);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Exclusive scan of N = V*T tile counts (one block).  status = {total, overflow, max tile count, 0}.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
+                                                     uint32_t* __restrict__ fill, int N, int T, int V,
+                                                     long long capacity, int* __restrict__ status,
+                                                     int* __restrict__ num_rendered)
+{
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t chunk_total;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint32_t carry = 0, maxc = 0;
+	for (int base = 0; base < N; base += 1024)
+	{
+		const int i = base + tid;
+		const uint32_t c = i < N ? cnt[i] : 0u;
+		maxc = c > maxc ? c : maxc;
+		uint32_t x = c;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1)
+		{
+			uint32_t y = __shfl_up(x, d, 64);
+			if (lane >= d) x += y;
+		}
+		if (lane == 63) wsum[wave] = x;
+		__syncthreads();
+		if (wave == 0)
+		{
+			uint32_t s = lane < 16 ? wsum[lane] : 0u;
+			uint32_t incl = s;
+#pragma unroll
+			for (int d = 1; d < 16; d <<= 1)
+			{
+				uint32_t y = __shfl_up(incl, d, 64);
+				if (lane >= d) incl += y;
+			}
+			if (lane < 16) wsum[lane] = incl - s;
+			if (lane == 15) chunk_total = incl;
+		}
+		__syncthreads();
+		if (i < N)
+		{
+			off[i] = carry + wsum[wave] + (x - c);
+			fill[i] = 0u;
+		}
+		carry += chunk_total;
+		__syncthreads();
+	}
+	// block max of maxc
+	{
+		int m = wave_max_i((int)maxc);
+		if (lane == 0) wsum[wave] = (uint32_t)m;
+		__syncthreads();
+		if (tid == 0)
+		{
+			uint32_t mm = 0;
+			for (int w = 0; w < 16; w++) mm = wsum[w] > mm ? wsum[w] : mm;
+			status[0] = (int)carry;
+			status[1] = ((long long)carry > capacity) ? 1 : 0;
+			status[2] = (int)mm;
+			status[3] = 0;
+		}
+	}
+	if (num_rendered)
+	{
+		__syncthreads();
+		for (int v = tid; v < V; v += 1024)
+		{
+			uint32_t a = off[(size_t)v * T];
+			uint32_t b = (v + 1 < V) ? off[(size_t)(v + 1) * T] : carry;
+			num_rendered[v] = (int)(b - a);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
+{
+	if (p.status[1]) return;
+	const int tid = threadIdx.x;
+	const int v = blockIdx.y;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t* off = p.tile_off + (size_t)v * p.T;
+	uint32_t* fill = p.tile_fill + (size_t)v * p.T;
+	for (int g = 0; g < FR_G_PER_THREAD; g++)
+	{
+		const int i = (blockIdx.x * FR_G_PER_THREAD + g) * FR_THREADS + tid;
+		if (i >= p.P) break;
+		const int rad = p.radii[vP + i];
+		if (rad > 0)
+		{
+			const fr_f2 xy = p.means2D[vP + i];
+			const uint64_t hi = ((uint64_t)fr_as_u32(p.depths[vP + i])) << 32;
+			const fr_rect rc = fr_get_rect(xy.x, xy.y, rad, p.gx, p.gy);
+			for (uint32_t y = rc.y0; y < rc.y1; y++)
+				for (uint32_t x = rc.x0; x < rc.x1; x++)
+				{
+					const uint32_t t = y * p.gx + x;
+					const uint32_t slot = off[t] + atomicAdd(&fill[t], 1u);
+					p.keys[slot] = hi | (uint32_t)i;
+				}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ascending-only bitonic network ("flip" form): works for any n without padding, because a comparator whose
+// upper element lies beyond n would compare against +inf and never swap.
+template <typename KeyPtr>
+__device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid)
+{
+	uint32_t n_pad = 1;
+	while (n_pad < n) n_pad <<= 1;
+	for (uint32_t k = 2; k <= n_pad; k <<= 1)
+	{
+		// flip stage: i <-> i ^ (k-1)
+		for (uint32_t t = tid; t < (n_pad >> 1); t += FR_THREADS)
+		{
+			const uint32_t half = k >> 1;
+			const uint32_t i = ((t / half) * k) + (t % half);
+			const uint32_t l = i ^ (k - 1);
+			if (l < n)
+			{
+				uint64_t a = keys[i], b = keys[l];
+				if (a > b) { keys[i] = b; keys[l] = a; }
+			}
+		}
+		__syncthreads();
+		for (uint32_t j = k >> 2; j > 0; j >>= 1)
+		{
+			for (uint32_t t = tid; t < (n_pad >> 1); t += FR_THREADS)
+			{
+				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+				const uint32_t l = i + j;
+				if (l < n)
+				{
+					uint64_t a = keys[i], b = keys[l];
+					if (a > b) { keys[i] = b; keys[l] = a; }
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
+{
+	if (p.status[1]) return;
+	__shared__ uint64_t skeys[FR_SORT_LDS_KEYS];
+	const int tid = threadIdx.x;
+	const size_t vt = (size_t)blockIdx.y * p.T + blockIdx.x;
+	const uint32_t n = p.tile_cnt[vt];
+	if (n < 2) return;
+	uint64_t* gk = p.keys + p.tile_off[vt];
+	if (n <= FR_SORT_LDS_KEYS)
+	{
+		for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
+		__syncthreads();
+		fr_bitonic(skeys, n, tid);
+		for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+	}
+	else
+	{
+		// rare: a tile with more splats than the LDS segment; same network straight on global memory
+		// (__syncthreads orders the workgroup's own global accesses)
+		fr_bitonic(gk, n, tid);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// alpha of one (pixel, splat) pair, rounded exactly like forward.cu:338-351 / the oracle.
+// Returns false when the pair is skipped.
+__device__ __forceinline__ bool fr_pair_alpha(float xyx, float xyy, float pfx, float pfy, float cx, float cy, float cz,
+                                              float o, float thr, float& dx, float& dy, float& G, float& alpha)
+{
+	dx = xyx - pfx; dy = xyy - pfy;
+	const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+	if (power > 0.0f) return false;
+	if (power < thr) return false;          // conservative: alpha < 1/255 for certain
+	G = fr_expf(power);
+	alpha = fminf(0.99f, o * G);
+	if (alpha < 1.0f / 255.0f) return false;
+	return true;
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const float* __restrict__ feat, int feat_view_stride,
+                                                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                               float* __restrict__ out_color, float* __restrict__ out_depth)
+{
+	if (p.status[1]) return;
+	__shared__ fr_f2 s_xy[FR_BATCH];
+	__shared__ fr_f4 s_co[FR_BATCH];
+	__shared__ float s_thr[FR_BATCH];
+	__shared__ float s_depth[FR_BATCH];
+	__shared__ float s_rgb[3][FR_BATCH];
+
+	const int tid = threadIdx.x;
+	const int v = blockIdx.y;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float* fv = feat + (size_t)v * feat_view_stride;
+
+	bool done = !inside;
+	float T = 1.0f;
+	uint32_t contributor = 0, last_contributor = 0;
+	float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+	float D = 15.0f;
+
+	for (uint32_t base = 0; base < n; base += FR_BATCH)
+	{
+		if (__syncthreads_count(done) == FR_THREADS) break;
+		const uint32_t k = base + tid;
+		if (k < n)
+		{
+			const uint64_t key = gk[k];
+			const uint32_t id = (uint32_t)key;
+			s_xy[tid] = p.means2D[vP + id];
+			const fr_f4 co = p.conic_op[vP + id];
+			s_co[tid] = co;
+			s_thr[tid] = fr_power_threshold(co.w);
+			s_depth[tid] = fr_as_f32((uint32_t)(key >> 32));
+			s_rgb[0][tid] = fv[3 * (size_t)id]; s_rgb[1][tid] = fv[3 * (size_t)id + 1]; s_rgb[2][tid] = fv[3 * (size_t)id + 2];
+		}
+		__syncthreads();
+		const int m = (int)min((uint32_t)FR_BATCH, n - base);
+		for (int j = 0; !done && j < m; j++)
+		{
+			contributor++;
+			const fr_f2 xy = s_xy[j];
+			const fr_f4 co = s_co[j];
+			float dx, dy, G, alpha;
+			if (!fr_pair_alpha(xy.x, xy.y, pfx, pfy, co.x, co.y, co.z, co.w, s_thr[j], dx, dy, G, alpha))
+				continue;
+			const float test_T = T * (1 - alpha);
+			if (test_T < 0.0001f)
+			{
+				done = true;
+				continue;
+			}
+			C0 += s_rgb[0][j] * alpha * T;
+			C1 += s_rgb[1][j] * alpha * T;
+			C2 += s_rgb[2][j] * alpha * T;
+			if (T > 0.5f && test_T < 0.5f) D = s_depth[j];
+			T = test_T;
+			last_contributor = contributor;
+		}
+	}
+	if (inside)
+	{
+		const size_t HW = (size_t)p.H * p.W;
+		const size_t pix = (size_t)p.W * pxy + pxx;
+		final_T[v * HW + pix] = T;
+		n_contrib[v * HW + pix] = last_contributor;
+		if (out_color)
+		{
+			out_color[(v * 3 + 0) * HW + pix] = C0 + T * p.bg[0];
+			out_color[(v * 3 + 1) * HW + pix] = C1 + T * p.bg[1];
+			out_color[(v * 3 + 2) * HW + pix] = C2 + T * p.bg[2];
+		}
+		if (out_depth) out_depth[v * HW + pix] = D;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-(pixel, splat) backward core shared by the Fisher scorer and the generic backward.
+// Updates the back-to-front recurrences and returns u = (m2x, m2y, cx, cy, cw), the colour weights and
+// the opacity gradient (backward.cu:978-1038).
+struct FrPixState {
+	float T, T_final;
+	float accum0, accum1, accum2;
+	float lastc0, lastc1, lastc2;
+	float last_alpha;
+};
+
+__device__ __forceinline__ void fr_pair_backward(FrPixState& s, float alpha, float G, float dx, float dy,
+                                                 float cx, float cy, float cz, float o,
+                                                 float c0, float c1, float c2, float g0, float g1, float g2,
+                                                 float bg_dot, float ddelx_dx, float ddely_dy,
+                                                 float& m2x, float& m2y, float& qx, float& qy, float& qw,
+                                                 float& wcol, float& gop)
+{
+#pragma clang fp contract(fast)
+	s.T = s.T / (1.f - alpha);
+	wcol = alpha * s.T;
+	float dL_dalpha;
+	s.accum0 = s.last_alpha * s.lastc0 + (1.f - s.last_alpha) * s.accum0; s.lastc0 = c0;
+	s.accum1 = s.last_alpha * s.lastc1 + (1.f - s.last_alpha) * s.accum1; s.lastc1 = c1;
+	s.accum2 = s.last_alpha * s.lastc2 + (1.f - s.last_alpha) * s.accum2; s.lastc2 = c2;
+	dL_dalpha = (c0 - s.accum0) * g0 + (c1 - s.accum1) * g1 + (c2 - s.accum2) * g2;
+	dL_dalpha *= s.T;
+	s.last_alpha = alpha;
+	dL_dalpha += (-s.T_final / (1.f - alpha)) * bg_dot;
+	const float dL_dG = o * dL_dalpha;
+	const float gdx = G * dx, gdy = G * dy;
+	const float dG_ddelx = -gdx * cx - gdy * cy;
+	const float dG_ddely = -gdy * cz - gdx * cy;
+	m2x = dL_dG * dG_ddelx * ddelx_dx;
+	m2y = dL_dG * dG_ddely * ddely_dy;
+	qx = -0.5f * gdx * dx * dL_dG;
+	qy = -0.5f * gdx * dy * dL_dG;
+	qw = -0.5f * gdy * dy * dL_dG;
+	gop = G * dL_dalpha;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused Fisher scorer: one workgroup per (tile, view).
+struct FrFisherArgs {
+	float dL;                    // constant upstream gradient
+	const float* H_inv; long long hinv_stride;
+	float* out_H; long long outH_stride;
+	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
+};
+
+template <int C, bool HAS_HINV, bool HAS_OUTH>
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisherArgs f)
+{
+	constexpr int NA = (C == 11) ? 36 : 15;   // Jacobian coefficients per splat
+	__shared__ fr_f2 s_xy[FR_BATCH];
+	__shared__ fr_f4 s_co[FR_BATCH];
+	__shared__ float s_thr[FR_BATCH];
+	__shared__ float s_rgb[3][FR_BWD_BATCH];
+	__shared__ float s_A[NA][FR_BWD_BATCH];
+	__shared__ float s_hinv[HAS_HINV ? C : 1][FR_BWD_BATCH];
+	__shared__ uint32_t s_id[FR_BWD_BATCH];
+	__shared__ float s_red[4];
+	__shared__ int s_redi[4];
+
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int v = blockIdx.y;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+
+	// ---- pass 1: transmittance only (forward.cu:331-380 without colour / depth) ----
+	bool done = !inside;
+	float T = 1.0f;
+	uint32_t contributor = 0, last_contributor = 0;
+	for (uint32_t base = 0; base < n; base += FR_BATCH)
+	{
+		if (__syncthreads_count(done) == FR_THREADS) break;
+		const uint32_t k = base + tid;
+		if (k < n)
+		{
+			const uint32_t id = (uint32_t)gk[k];
+			s_xy[tid] = p.means2D[vP + id];
+			const fr_f4 co = p.conic_op[vP + id];
+			s_co[tid] = co;
+			s_thr[tid] = fr_power_threshold(co.w);
+		}
+		__syncthreads();
+		const int m = (int)min((uint32_t)FR_BATCH, n - base);
+		for (int j = 0; !done && j < m; j++)
+		{
+			contributor++;
+			const fr_f2 xy = s_xy[j];
+			const fr_f4 co = s_co[j];
+			float dx, dy, G, alpha;
+			if (!fr_pair_alpha(xy.x, xy.y, pfx, pfy, co.x, co.y, co.z, co.w, s_thr[j], dx, dy, G, alpha))
+				continue;
+			const float test_T = T * (1 - alpha);
+			if (test_T < 0.0001f) { done = true; continue; }
+			T = test_T;
+			last_contributor = contributor;
+		}
+	}
+	const int last = inside ? (int)last_contributor : 0;
+	// tile-wide maximum of last_contributor: nothing behind it is touched by the backward
+	{
+		int m = wave_max_i(last);
+		__syncthreads();
+		if (lane == 0) s_redi[wave] = m;
+		__syncthreads();
+	}
+	int remaining = max(max(s_redi[0], s_redi[1]), max(s_redi[2], s_redi[3]));
+
+	// ---- pass 2: back to front (backward.cu:939-1138), per-pixel leaf gradients squared on the fly ----
+	float vm[16], pm[16], wm[12];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const bool has_w2c = p.w2c != nullptr;
+	if (has_w2c)
+	{
+#pragma unroll
+		for (int k = 0; k < 12; k++) wm[k] = p.w2c[16 * (size_t)v + k];
+	}
+	FrPixState st;
+	st.T_final = inside ? T : 0.f;
+	st.T = st.T_final;
+	st.accum0 = st.accum1 = st.accum2 = 0.f;
+	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
+	st.last_alpha = 0.f;
+	const float g = f.dL;
+	const float bg_dot = p.bg[0] * g + p.bg[1] * g + p.bg[2] * g;
+	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+	float score = 0.f;
+
+	while (remaining > 0)
+	{
+		const int m = min(FR_BWD_BATCH, remaining);
+		__syncthreads();
+		if (tid < m)
+		{
+			const uint32_t id = (uint32_t)gk[remaining - 1 - tid];
+			s_id[tid] = id;
+			s_xy[tid] = p.means2D[vP + id];
+			const fr_f4 co = p.conic_op[vP + id];
+			s_co[tid] = co;
+			s_thr[tid] = fr_power_threshold(co.w);
+			s_rgb[0][tid] = p.colors[3 * (size_t)id]; s_rgb[1][tid] = p.colors[3 * (size_t)id + 1]; s_rgb[2][tid] = p.colors[3 * (size_t)id + 2];
+			fr_f3 pw = { p.means3D[3 * (size_t)id], p.means3D[3 * (size_t)id + 1], p.means3D[3 * (size_t)id + 2] };
+			fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+			float c3[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)id + k];
+			float A[3][5];
+			float B[6][3];
+			fr_mean_jacobian(po, c3, vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int c = 0; c < 5; c++) s_A[r * 5 + c][tid] = A[r][c];
+			if constexpr (C == 11)
+			{
+				fr_f3 sc = { p.scales[3 * (size_t)id], p.scales[3 * (size_t)id + 1], p.scales[3 * (size_t)id + 2] };
+				fr_f4 q = { p.rots[4 * (size_t)id], p.rots[4 * (size_t)id + 1], p.rots[4 * (size_t)id + 2], p.rots[4 * (size_t)id + 3] };
+				float Cm[7][3];
+				fr_scale_rot_jacobian(sc, p.mod, q, B, Cm);
+#pragma unroll
+				for (int r = 0; r < 7; r++)
+#pragma unroll
+					for (int c = 0; c < 3; c++) s_A[15 + r * 3 + c][tid] = Cm[r][c];
+			}
+			if constexpr (HAS_HINV)
+			{
+				const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
+#pragma unroll
+				for (int c = 0; c < C; c++) s_hinv[c][tid] = hp[c];
+			}
+		}
+		__syncthreads();
+		for (int j = 0; j < m; j++)
+		{
+			const int k = remaining - 1 - j;     // 0-based position in the tile's list == `contributor`
+			bool act = inside && (k < last);
+			if (!__any(act)) continue;
+			const fr_f2 xy = s_xy[j];
+			const fr_f4 co = s_co[j];
+			float dx, dy, G = 0.f, alpha = 0.f;
+			act = act && fr_pair_alpha(xy.x, xy.y, pfx, pfy, co.x, co.y, co.z, co.w, s_thr[j], dx, dy, G, alpha);
+			if (!__any(act)) continue;
+			float leaf2[C];
+#pragma unroll
+			for (int c = 0; c < C; c++) leaf2[c] = 0.f;
+			if (act)
+			{
+				float m2x, m2y, qx, qy, qw, wcol, gop;
+				fr_pair_backward(st, alpha, G, dx, dy, co.x, co.y, co.z, co.w,
+				                 s_rgb[0][j], s_rgb[1][j], s_rgb[2][j], g, g, g, bg_dot, ddelx_dx, ddely_dy,
+				                 m2x, m2y, qx, qy, qw, wcol, gop);
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+				{
+					const float l = s_A[r * 5 + 0][j] * m2x + s_A[r * 5 + 1][j] * m2y + s_A[r * 5 + 2][j] * qx
+					              + s_A[r * 5 + 3][j] * qy + s_A[r * 5 + 4][j] * qw;
+					leaf2[r] = l * l;
+				}
+				leaf2[3] = gop * gop;
+				if constexpr (C == 11)
+				{
+#pragma unroll
+					for (int r = 0; r < 7; r++)
+					{
+						const float l = s_A[15 + r * 3 + 0][j] * qx + s_A[15 + r * 3 + 1][j] * qy + s_A[15 + r * 3 + 2][j] * qw;
+						leaf2[4 + r] = l * l;
+					}
+				}
+				if constexpr (HAS_HINV)
+				{
+#pragma unroll
+					for (int c = 0; c < C; c++) score += leaf2[c] * s_hinv[c][j];
+				}
+			}
+			if constexpr (HAS_OUTH)
+			{
+				// sum over the wave's pixels, then one atomic per column (the reference: one per pixel per column)
+				float mine = 0.f;
+#pragma unroll
+				for (int c = 0; c < C; c++)
+				{
+					const float s = wave_sum(leaf2[c]);
+					if (lane == c) mine = s;
+				}
+				if (lane < C && mine != 0.f)
+					atomicAdd(f.out_H + (size_t)v * f.outH_stride + (size_t)s_id[j] * C + lane, mine);
+			}
+		}
+		remaining -= m;
+	}
+	if constexpr (HAS_HINV)
+	{
+		const float ws = wave_sum(score);
+		__syncthreads();
+		if (lane == 0) s_red[wave] = ws;
+		__syncthreads();
+		if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+	}
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
+                                                              const int* __restrict__ status, float* __restrict__ out_scores)
+{
+	if (status[1]) return;
+	__shared__ double s_part[FR_THREADS];
+	const int v = blockIdx.x, tid = threadIdx.x;
+	double s = 0.0;
+	for (int t = tid; t < T; t += FR_THREADS) s += (double)tile_scores[(size_t)v * T + t];
+	s_part[tid] = s;
+	__syncthreads();
+	for (int o = FR_THREADS / 2; o > 0; o >>= 1)
+	{
+		if (tid < o) s_part[tid] += s_part[tid + o];
+		__syncthreads();
+	}
+	if (tid == 0) out_scores[v] = (float)s_part[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic fused backward of ONE view with grad_power (renderCUDAFused, backward.cu:850-1140).
+struct FrBwdArgs {
+	const float* dL_dpix;        // [3][H][W]
+	const float* final_T; const uint32_t* n_contrib;
+	const float* colors;         // colors_precomp or rgb from SH
+	int power;
+	float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolors; float* dL_dmean3D;
+	float* dL_dcov3D; float* dL_dscale; float* dL_drot;
+};
+
+__device__ __forceinline__ float fr_powi(float x, int power)
+{
+	if (power == 1) return x;
+	if (power == 2) return x * x;
+	return powf(x, (float)power);
+}
+
+template <bool HAS_SR>
+__global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdArgs b)
+{
+	constexpr int NA = 15 + 18 + (HAS_SR ? 21 : 0);
+	constexpr int NL = 18 + (HAS_SR ? 7 : 0);   // leaves: m2(2) conic(3) col(3) op(1) mean(3) cov(6) [scale(3) rot(4)]
+	__shared__ fr_f2 s_xy[FR_BWD_BATCH];
+	__shared__ fr_f4 s_co[FR_BWD_BATCH];
+	__shared__ float s_thr[FR_BWD_BATCH];
+	__shared__ float s_rgb[3][FR_BWD_BATCH];
+	__shared__ float s_A[NA][FR_BWD_BATCH];
+	__shared__ uint32_t s_id[FR_BWD_BATCH];
+
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const uint32_t n = p.tile_cnt[tile];
+	const uint64_t* gk = p.keys + p.tile_off[tile];
+	const size_t HW = (size_t)p.H * p.W;
+	const size_t pix = (size_t)p.W * pxy + pxx;
+
+	float vm[16], pm[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+
+	FrPixState st;
+	st.T_final = inside ? b.final_T[pix] : 0.f;
+	st.T = st.T_final;
+	st.accum0 = st.accum1 = st.accum2 = 0.f;
+	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
+	st.last_alpha = 0.f;
+	const int last = inside ? (int)b.n_contrib[pix] : 0;
+	float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+	if (inside) { g0 = b.dL_dpix[pix]; g1 = b.dL_dpix[HW + pix]; g2 = b.dL_dpix[2 * HW + pix]; }
+	const float bg_dot = p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2;
+	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+	const int power = b.power;
+
+	int remaining = (int)n;
+	while (remaining > 0)
+	{
+		const int m = min(FR_BWD_BATCH, remaining);
+		__syncthreads();
+		if (tid < m)
+		{
+			const uint32_t id = (uint32_t)gk[remaining - 1 - tid];
+			s_id[tid] = id;
+			s_xy[tid] = p.means2D[id];
+			const fr_f4 co = p.conic_op[id];
+			s_co[tid] = co;
+			s_thr[tid] = fr_power_threshold(co.w);
+			s_rgb[0][tid] = b.colors[3 * (size_t)id]; s_rgb[1][tid] = b.colors[3 * (size_t)id + 1]; s_rgb[2][tid] = b.colors[3 * (size_t)id + 2];
+			fr_f3 po = { p.means3D[3 * (size_t)id], p.means3D[3 * (size_t)id + 1], p.means3D[3 * (size_t)id + 2] };
+			float c3[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)id + k];
+			float A[3][5];
+			float B[6][3];
+			fr_mean_jacobian(po, c3, vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, B);
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int c = 0; c < 5; c++) s_A[r * 5 + c][tid] = A[r][c];
+#pragma unroll
+			for (int r = 0; r < 6; r++)
+#pragma unroll
+				for (int c = 0; c < 3; c++) s_A[15 + r * 3 + c][tid] = B[r][c];
+			if constexpr (HAS_SR)
+			{
+				fr_f3 sc = { p.scales[3 * (size_t)id], p.scales[3 * (size_t)id + 1], p.scales[3 * (size_t)id + 2] };
+				fr_f4 q = { p.rots[4 * (size_t)id], p.rots[4 * (size_t)id + 1], p.rots[4 * (size_t)id + 2], p.rots[4 * (size_t)id + 3] };
+				float Cm[7][3];
+				fr_scale_rot_jacobian(sc, p.mod, q, B, Cm);
+#pragma unroll
+				for (int r = 0; r < 7; r++)
+#pragma unroll
+					for (int c = 0; c < 3; c++) s_A[33 + r * 3 + c][tid] = Cm[r][c];
+			}
+		}
+		__syncthreads();
+		for (int j = 0; j < m; j++)
+		{
+			const int k = remaining - 1 - j;
+			bool act = inside && (k < last);
+			if (!__any(act)) continue;
+			const fr_f2 xy = s_xy[j];
+			const fr_f4 co = s_co[j];
+			float dx, dy, G = 0.f, alpha = 0.f;
+			act = act && fr_pair_alpha(xy.x, xy.y, pfx, pfy, co.x, co.y, co.z, co.w, s_thr[j], dx, dy, G, alpha);
+			if (!__any(act)) continue;
+			float leaf[NL];
+#pragma unroll
+			for (int c = 0; c < NL; c++) leaf[c] = 0.f;
+			if (act)
+			{
+				float m2x, m2y, qx, qy, qw, wcol, gop;
+				fr_pair_backward(st, alpha, G, dx, dy, co.x, co.y, co.z, co.w,
+				                 s_rgb[0][j], s_rgb[1][j], s_rgb[2][j], g0, g1, g2, bg_dot, ddelx_dx, ddely_dy,
+				                 m2x, m2y, qx, qy, qw, wcol, gop);
+				leaf[0] = fr_powi(m2x, power); leaf[1] = fr_powi(m2y, power);
+				leaf[2] = fr_powi(qx, power); leaf[3] = fr_powi(qy, power); leaf[4] = fr_powi(qw, power);
+				leaf[5] = fr_powi(wcol * g0, power); leaf[6] = fr_powi(wcol * g1, power); leaf[7] = fr_powi(wcol * g2, power);
+				leaf[8] = fr_powi(gop, power);
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+					leaf[9 + r] = fr_powi(s_A[r * 5 + 0][j] * m2x + s_A[r * 5 + 1][j] * m2y + s_A[r * 5 + 2][j] * qx
+					                      + s_A[r * 5 + 3][j] * qy + s_A[r * 5 + 4][j] * qw, power);
+#pragma unroll
+				for (int r = 0; r < 6; r++)
+					leaf[12 + r] = fr_powi(s_A[15 + r * 3 + 0][j] * qx + s_A[15 + r * 3 + 1][j] * qy + s_A[15 + r * 3 + 2][j] * qw, power);
+				if constexpr (HAS_SR)
+				{
+#pragma unroll
+					for (int r = 0; r < 7; r++)
+						leaf[18 + r] = fr_powi(s_A[33 + r * 3 + 0][j] * qx + s_A[33 + r * 3 + 1][j] * qy + s_A[33 + r * 3 + 2][j] * qw, power);
+				}
+			}
+			float mine = 0.f;
+#pragma unroll
+			for (int c = 0; c < NL; c++)
+			{
+				const float s = wave_sum(leaf[c]);
+				if (lane == c) mine = s;
+			}
+			if (lane < NL && mine != 0.f)
+			{
+				const size_t id = s_id[j];
+				float* dst;
+				if (lane < 2) dst = b.dL_dmean2D + 3 * id + lane;
+				else if (lane < 5) dst = b.dL_dconic + 4 * id + (lane == 4 ? 3 : lane - 2);
+				else if (lane < 8) dst = b.dL_dcolors + 3 * id + (lane - 5);
+				else if (lane < 9) dst = b.dL_dopacity + id;
+				else if (lane < 12) dst = b.dL_dmean3D + 3 * id + (lane - 9);
+				else if (lane < 18) dst = b.dL_dcov3D + 6 * id + (lane - 12);
+				else if (lane < 21) dst = b.dL_dscale + 3 * id + (lane - 18);
+				else dst = b.dL_drot + 4 * id + (lane - 21);
+				atomicAdd(dst, mine);
+			}
+		}
+		remaining -= m;
+	}
+}
+
+// =========================================================================================================
+// host side
+// =========================================================================================================
+static inline size_t fr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct FrLayout {
+	// geometry
+	size_t depths, means2D, conic_op, cov3D, rgb, clamped, geom_bytes;
+	// image
+	size_t tile_cnt, tile_off, tile_fill, final_T, n_contrib, status, img_bytes;
+	// binning
+	size_t keys, bin_bytes;
+};
+
+static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered)
+{
+	FrLayout L;
+	const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
+	const size_t VP = (size_t)(V * P);
+	size_t o = 0;
+	L.depths = o; o = fr_align(o + VP * 4);
+	L.means2D = o; o = fr_align(o + VP * 8);
+	L.conic_op = o; o = fr_align(o + VP * 16);
+	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
+	L.rgb = o; o = fr_align(o + VP * 12);
+	L.clamped = o; o = fr_align(o + VP * 3);
+	L.geom_bytes = o > 0 ? o : 256;
+	o = 0;
+	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.tile_off = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.tile_fill = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.final_T = o; o = fr_align(o + (size_t)(V * W * H) * 4);
+	L.n_contrib = o; o = fr_align(o + (size_t)(V * W * H) * 4);
+	L.status = o; o = fr_align(o + 64);
+	L.img_bytes = o;
+	L.keys = 0;
+	L.bin_bytes = fr_align((size_t)(max_rendered > 0 ? max_rendered : 1) * 8);
+	return L;
+}
+
+extern "C" int fr_version(void) { return FR_VERSION; }
+extern "C" const char* fr_last_error(void) { return g_err; }
+
+extern "C" int fr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t out[3])
+{
+	if (P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out) return fr_fail(FR_EINVAL, "fr_workspace_bytes: bad argument");
+	FrLayout L = fr_layout(P, W, H, 1, max_rendered);
+	out[0] = L.geom_bytes; out[1] = L.bin_bytes; out[2] = L.img_bytes;
+	return FR_OK;
+}
+
+extern "C" int fr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t o[13])
+{
+	if (P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !o) return fr_fail(FR_EINVAL, "fr_workspace_layout: bad argument");
+	FrLayout L = fr_layout(P, W, H, 1, max_rendered);
+	o[0] = L.depths; o[1] = L.means2D; o[2] = L.conic_op; o[3] = L.cov3D; o[4] = L.rgb; o[5] = L.clamped;
+	o[6] = L.tile_cnt; o[7] = L.tile_off; o[8] = L.tile_fill; o[9] = L.final_T; o[10] = L.n_contrib; o[11] = L.status;
+	o[12] = L.keys;
+	return FR_OK;
+}
+
+extern "C" int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                               uint8_t* present, fr_stream_t stream)
+{
+	(void)projmatrix;
+	if (P < 0) return fr_fail(FR_EINVAL, "fr_mark_visible: P < 0");
+	if (P == 0) return FR_OK;
+	if (!means3D || !viewmatrix || !present) return fr_fail(FR_EINVAL, "fr_mark_visible: null pointer");
+	hipLaunchKernelGGL(k_mark_visible, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, (hipStream_t)stream,
+	                   P, means3D, viewmatrix, present);
+	return fr_check_launch("k_mark_visible");
+}
+
+static int fr_validate(const fr_raster_cfg* cfg, const fr_gaussians* g, const char* who, bool need_opacity = true)
+{
+	static thread_local char buf[256];
+	if (!cfg || !g) { snprintf(buf, sizeof(buf), "%s: null cfg/gaussians", who); return fr_fail(FR_EINVAL, buf); }
+	if (cfg->P < 0 || cfg->image_width <= 0 || cfg->image_height <= 0) { snprintf(buf, sizeof(buf), "%s: bad P/W/H", who); return fr_fail(FR_EINVAL, buf); }
+	if (cfg->P == 0) return FR_OK;
+	if (!g->means3D || (need_opacity && !g->opacities) || !cfg->bg || !cfg->viewmatrix || !cfg->projmatrix)
+	{ snprintf(buf, sizeof(buf), "%s: null means3D/opacities/bg/viewmatrix/projmatrix", who); return fr_fail(FR_EINVAL, buf); }
+	if ((g->colors_precomp == nullptr) == (g->shs == nullptr))
+	{ snprintf(buf, sizeof(buf), "%s: provide exactly one of SHs or precomputed colors", who); return fr_fail(FR_EINVAL, buf); }
+	if (g->shs && (!cfg->campos || cfg->sh_coeffs <= 0 || (cfg->sh_degree + 1) * (cfg->sh_degree + 1) > cfg->sh_coeffs || cfg->sh_degree > 3 || cfg->sh_degree < 0))
+	{ snprintf(buf, sizeof(buf), "%s: bad SH degree / coefficient count / campos", who); return fr_fail(FR_EINVAL, buf); }
+	const bool sr = g->scales && g->rotations;
+	if ((sr ? 1 : 0) + (g->cov3D_precomp ? 1 : 0) != 1 || ((g->scales != nullptr) != (g->rotations != nullptr)))
+	{ snprintf(buf, sizeof(buf), "%s: provide exactly one of scale/rotation pair or precomputed 3D covariance", who); return fr_fail(FR_EINVAL, buf); }
+	return FR_OK;
+}
+
+static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gaussians* g, int V)
+{
+	memset(&p, 0, sizeof(p));
+	p.P = cfg->P; p.V = V; p.W = cfg->image_width; p.H = cfg->image_height;
+	p.gx = (uint32_t)((p.W + 15) / 16); p.gy = (uint32_t)((p.H + 15) / 16); p.T = (int)(p.gx * p.gy);
+	p.tanfovx = cfg->tanfovx; p.tanfovy = cfg->tanfovy;
+	p.focal_y = p.H / (2.0f * cfg->tanfovy);   // rasterizer_impl.cu:222-223
+	p.focal_x = p.W / (2.0f * cfg->tanfovx);
+	p.mod = cfg->scale_modifier; p.D = cfg->sh_degree; p.M = cfg->sh_coeffs;
+	p.bg = cfg->bg; p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
+	p.means3D = g->means3D; p.colors = g->colors_precomp; p.shs = g->shs; p.opac = g->opacities;
+	p.scales = g->scales; p.rots = g->rotations;
+}
+
+// Launches cov3d, preprocess, scan, scatter, sort for V views.  p must carry the carved buffers.
+static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
+{
+	int rc;
+	const int P = p.P;
+	(void)hipMemsetAsync(p.tile_cnt, 0, (size_t)p.V * p.T * 4, s);
+	(void)hipMemsetAsync(p.status, 0, 16, s);
+	if (p.vis_count) (void)hipMemsetAsync(p.vis_count, 0, (size_t)p.V * 4, s);
+	if (g->cov3D_precomp) p.cov3D = g->cov3D_precomp;
+	else
+	{
+		hipLaunchKernelGGL(k_cov3d, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, s, P, g->scales, p.mod, g->rotations, p.cov3D_out);
+		if ((rc = fr_check_launch("k_cov3d"))) return rc;
+		p.cov3D = p.cov3D_out;
+	}
+	const int per_block = FR_THREADS * FR_G_PER_THREAD;
+	dim3 gridP((P + per_block - 1) / per_block, p.V);
+	hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), 0, s, p);
+	if ((rc = fr_check_launch("k_preprocess"))) return rc;
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
+	                   p.key_capacity, p.status, p.num_rendered);
+	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
+	hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 0, s, p);
+	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
+	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T, p.V), dim3(FR_THREADS), 0, s, p);
+	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
+	return FR_OK;
+}
+
+static void fr_carve_single(FrParams& p, const FrLayout& L, char* geom, char* bin, char* img)
+{
+	p.depths = (float*)(geom + L.depths);
+	p.means2D = (fr_f2*)(geom + L.means2D);
+	p.conic_op = (fr_f4*)(geom + L.conic_op);
+	p.cov3D_out = (float*)(geom + L.cov3D);
+	p.rgb = (float*)(geom + L.rgb);
+	p.clamped = (uint8_t*)(geom + L.clamped);
+	p.tile_cnt = (uint32_t*)(img + L.tile_cnt);
+	p.tile_off = (uint32_t*)(img + L.tile_off);
+	p.tile_fill = (uint32_t*)(img + L.tile_fill);
+	p.status = (int*)(img + L.status);
+	p.keys = (uint64_t*)(bin + L.keys);
+}
+
+extern "C" int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,
+                          void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
+                          float* out_color, float* out_depth, int32_t* radii, int32_t* status, fr_stream_t stream)
+{
+	int rc = fr_validate(cfg, g, "fr_forward");
+	if (rc) return rc;
+	hipStream_t s = (hipStream_t)stream;
+	const int P = cfg->P, W = cfg->image_width, H = cfg->image_height;
+	if (!out_color || !out_depth || !status) return fr_fail(FR_EINVAL, "fr_forward: null output");
+	if (P == 0)
+	{
+		// rasterize_points.cu:67-81: outputs stay zero, nothing is launched
+		(void)hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
+		(void)hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
+		(void)hipMemsetAsync(status, 0, 16, s);
+		return FR_OK;
+	}
+	if (!geom_ws || !binning_ws || !image_ws || !radii || binning_capacity < 0) return fr_fail(FR_EINVAL, "fr_forward: null workspace / radii");
+	FrLayout L = fr_layout(P, W, H, 1, binning_capacity);
+	FrParams p;
+	fr_fill_params(p, cfg, g, 1);
+	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
+	p.radii = radii;
+	p.key_capacity = binning_capacity;
+	if ((rc = fr_bin_pipeline(p, g, s))) return rc;
+	const float* feat = g->colors_precomp ? g->colors_precomp : p.rgb;
+	hipLaunchKernelGGL(k_render_forward, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0,
+	                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_color, out_depth);
+	if ((rc = fr_check_launch("k_render_forward"))) return rc;
+	(void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
+	return FR_OK;
+}
+
+extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                           const void* geom_ws, const void* binning_ws, const void* image_ws,
+                           const float* dL_dout_color, int32_t power,
+                           float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
+                           fr_stream_t stream)
+{
+	int rc = fr_validate(cfg, g, "fr_backward", false);
+	if (rc) return rc;
+	hipStream_t s = (hipStream_t)stream;
+	const int P = cfg->P, W = cfg->image_width, H = cfg->image_height;
+	if (P == 0) return FR_OK;
+	if (!geom_ws || !binning_ws || !image_ws || !radii || !dL_dout_color || !dL_dmeans2D || !dL_dcolors || !dL_dopacity ||
+	    !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_dconic)
+		return fr_fail(FR_EINVAL, "fr_backward: null pointer");
+	if (g->shs)
+		return fr_fail(FR_EINVAL, "fr_backward: spherical-harmonics colours are forward-only in this build (the reference's callers always pass colors_precomp)");
+	(void)hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s);
+	(void)hipMemsetAsync(dL_dmeans3D, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dcov3D, 0, (size_t)P * 6 * 4, s);
+	(void)hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_drotations, 0, (size_t)P * 4 * 4, s);
+	(void)hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * 4, s);
+	if (dL_dsh && cfg->sh_coeffs > 0) (void)hipMemsetAsync(dL_dsh, 0, (size_t)P * cfg->sh_coeffs * 3 * 4, s);
+
+	FrLayout L = fr_layout(P, W, H, 1, 1);
+	FrParams p;
+	fr_fill_params(p, cfg, g, 1);
+	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
+	p.radii = (int*)radii;
+	p.cov3D = g->cov3D_precomp ? g->cov3D_precomp : p.cov3D_out;
+	FrBwdArgs b;
+	b.dL_dpix = dL_dout_color;
+	b.final_T = (const float*)((const char*)image_ws + L.final_T);
+	b.n_contrib = (const uint32_t*)((const char*)image_ws + L.n_contrib);
+	b.colors = g->colors_precomp ? g->colors_precomp : p.rgb;
+	b.power = power;
+	b.dL_dmean2D = dL_dmeans2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolors = dL_dcolors;
+	b.dL_dmean3D = dL_dmeans3D; b.dL_dcov3D = dL_dcov3D; b.dL_dscale = dL_dscales; b.dL_drot = dL_drotations;
+	if (g->scales)
+		hipLaunchKernelGGL(k_backward_tile<true>, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, b);
+	else
+		hipLaunchKernelGGL(k_backward_tile<false>, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, b);
+	return fr_check_launch("k_backward_tile");
+}
+
+// ---- fused Fisher scorer ---------------------------------------------------------------------------------
+struct FrFisherLayout {
+	size_t radii, depths, means2D, conic_op, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, total;
+};
+static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered)
+{
+	FrFisherLayout L;
+	const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
+	const size_t VP = (size_t)(V * P);
+	size_t o = 0;
+	L.radii = o; o = fr_align(o + VP * 4);
+	L.depths = o; o = fr_align(o + VP * 4);
+	L.means2D = o; o = fr_align(o + VP * 8);
+	L.conic_op = o; o = fr_align(o + VP * 16);
+	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
+	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.tile_off = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.tile_fill = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.tile_scores = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.status = o; o = fr_align(o + 64);
+	L.keys = o; o = fr_align(o + (size_t)(max_rendered > 0 ? max_rendered : 1) * 8);
+	L.total = o;
+	return L;
+}
+
+extern "C" size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered)
+{
+	if (P < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0) return 0;
+	return fr_fisher_layout(P, W, H, n_views, max_rendered).total;
+}
+
+template <int C>
+static void fr_launch_fisher(const FrParams& p, const FrFisherArgs& f, hipStream_t s)
+{
+	dim3 grid(p.T, p.V), block(FR_THREADS);
+	const bool hi = f.H_inv != nullptr, ho = f.out_H != nullptr;
+	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile<C, true, true>), grid, block, 0, s, p, f);
+	else if (hi) hipLaunchKernelGGL((k_fisher_tile<C, true, false>), grid, block, 0, s, p, f);
+	else hipLaunchKernelGGL((k_fisher_tile<C, false, true>), grid, block, 0, s, p, f);
+}
+
+extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, const fr_fisher_cfg* fc,
+                               void* workspace, size_t workspace_bytes, int64_t max_rendered,
+                               int32_t* status, fr_stream_t stream)
+{
+	int rc = fr_validate(cfg, g, "fr_fisher_views");
+	if (rc) return rc;
+	if (!fc || fc->n_views <= 0 || !fc->w2c || !status) return fr_fail(FR_EINVAL, "fr_fisher_views: bad fisher cfg");
+	if (fc->columns != 4 && fc->columns != 11) return fr_fail(FR_EINVAL, "fr_fisher_views: columns must be 4 or 11");
+	if (!g->colors_precomp) return fr_fail(FR_EINVAL, "fr_fisher_views: needs colors_precomp (the reference always passes rgb_colors)");
+	if (fc->columns == 11 && !(g->scales && g->rotations)) return fr_fail(FR_EINVAL, "fr_fisher_views: columns=11 needs scales and rotations");
+	if (fc->out_scores && !fc->H_inv) return fr_fail(FR_EINVAL, "fr_fisher_views: out_scores needs H_inv");
+	if (!fc->H_inv && !fc->out_H) return fr_fail(FR_EINVAL, "fr_fisher_views: nothing to compute (no H_inv and no out_H)");
+	if (fc->H_inv && !fc->out_scores) return fr_fail(FR_EINVAL, "fr_fisher_views: H_inv without out_scores");
+	const int P = cfg->P, W = cfg->image_width, H = cfg->image_height, V = fc->n_views;
+	hipStream_t s = (hipStream_t)stream;
+	if (P == 0)
+	{
+		if (fc->out_scores) (void)hipMemsetAsync(fc->out_scores, 0, (size_t)V * 4, s);
+		if (fc->out_vis_count) (void)hipMemsetAsync(fc->out_vis_count, 0, (size_t)V * 4, s);
+		if (fc->out_num_rendered) (void)hipMemsetAsync(fc->out_num_rendered, 0, (size_t)V * 4, s);
+		(void)hipMemsetAsync(status, 0, 16, s);
+		return FR_OK;
+	}
+	FrFisherLayout L = fr_fisher_layout(P, W, H, V, max_rendered);
+	if (!workspace || workspace_bytes < L.total) return fr_fail(FR_ENOSPACE, "fr_fisher_views: workspace smaller than fr_fisher_workspace_bytes()");
+	char* ws = (char*)workspace;
+	FrParams p;
+	fr_fill_params(p, cfg, g, V);
+	p.w2c = fc->w2c;
+	p.radii = (int*)(ws + L.radii);
+	p.depths = (float*)(ws + L.depths);
+	p.means2D = (fr_f2*)(ws + L.means2D);
+	p.conic_op = (fr_f4*)(ws + L.conic_op);
+	p.cov3D_out = (float*)(ws + L.cov3D);
+	p.tile_cnt = (uint32_t*)(ws + L.tile_cnt);
+	p.tile_off = (uint32_t*)(ws + L.tile_off);
+	p.tile_fill = (uint32_t*)(ws + L.tile_fill);
+	p.status = (int*)(ws + L.status);
+	p.keys = (uint64_t*)(ws + L.keys);
+	p.key_capacity = max_rendered;
+	p.vis_count = fc->out_vis_count;
+	p.num_rendered = fc->out_num_rendered;
+	if ((rc = fr_bin_pipeline(p, g, s))) return rc;
+
+	FrFisherArgs f;
+	f.dL = fc->dL_dpix;
+	f.H_inv = fc->H_inv; f.hinv_stride = fc->H_inv_view_stride;
+	f.out_H = fc->out_H; f.outH_stride = fc->out_H_view_stride;
+	f.tile_scores = (float*)(ws + L.tile_scores);
+	if (fc->columns == 4) fr_launch_fisher<4>(p, f, s);
+	else fr_launch_fisher<11>(p, f, s);
+	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
+	if (fc->out_scores)
+	{
+		hipLaunchKernelGGL(k_reduce_scores, dim3(V), dim3(FR_THREADS), 0, s, f.tile_scores, p.T, p.status, fc->out_scores);
+		if ((rc = fr_check_launch("k_reduce_scores"))) return rc;
+	}
+	(void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
+	return FR_OK;
+}
+
+// =========================================================================================================
+// simple-knn: distCUDA2.  Upstream (gitlab.inria.fr/bkerbl/simple-knn, not vendored in the reference) orders the
+// points along a Morton curve, boxes them 1024 at a time and prunes boxes by their distance to the query; the
+// result is the EXACT mean squared distance to the 3 nearest other points, so any exact search reproduces it.
+// Here: Morton keys -> multi-block bitonic network (same ascending-only network as the tile sort) -> box AABBs
+// -> one thread per point scanning the boxes that can still improve its third-best distance.
+// =========================================================================================================
+#define FR_KNN_BOX 1024
+#define FR_KNN_CHUNK 2048
+
+__device__ __forceinline__ uint32_t fr_enc_f(float f)
+{
+	uint32_t u = fr_as_u32(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fr_dec_f(uint32_t e)
+{
+	return fr_as_f32((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_knn_minmax(int P, const float* __restrict__ pts, uint32_t* __restrict__ mm)
+{
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (int i = blockIdx.x * FR_THREADS + threadIdx.x; i < P; i += gridDim.x * FR_THREADS)
+#pragma unroll
+		for (int a = 0; a < 3; a++) { float x = pts[3 * (size_t)i + a]; lo[a] = fminf(lo[a], x); hi[a] = fmaxf(hi[a], x); }
+#pragma unroll
+	for (int a = 0; a < 3; a++)
+	{
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&mm[a], fr_enc_f(lo[a])); atomicMax(&mm[3 + a], fr_enc_f(hi[a])); }
+	}
+}
+
+__device__ __forceinline__ uint32_t fr_spread10(uint32_t x)
+{
+	x = (x | (x << 16)) & 0x030000FF;
+	x = (x | (x << 8)) & 0x0300F00F;
+	x = (x | (x << 4)) & 0x030C30C3;
+	x = (x | (x << 2)) & 0x09249249;
+	return x;
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_knn_morton(int P, const float* __restrict__ pts, const uint32_t* __restrict__ mm,
+                                                           uint64_t* __restrict__ keys)
+{
+	int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= P) return;
+	uint32_t code = 0;
+#pragma unroll
+	for (int a = 0; a < 3; a++)
+	{
+		const float lo = fr_dec_f(mm[a]), hi = fr_dec_f(mm[3 + a]);
+		const float ext = hi - lo;
+		float u = ext > 0.f ? (pts[3 * (size_t)i + a] - lo) / ext : 0.f;
+		u = fminf(fmaxf(u, 0.f), 1.f);
+		code |= fr_spread10((uint32_t)(u * 1023.0f)) << a;
+	}
+	keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+}
+
+// sort each FR_KNN_CHUNK-aligned chunk completely in LDS (stages k = 2 .. FR_KNN_CHUNK)
+__global__ __launch_bounds__(FR_THREADS) void k_bitonic_chunk_sort(uint64_t* __restrict__ keys, uint32_t n)
+{
+	__shared__ uint64_t sk[FR_KNN_CHUNK];
+	const uint32_t base = blockIdx.x * FR_KNN_CHUNK;
+	const uint32_t m = min((uint32_t)FR_KNN_CHUNK, n - base);
+	for (uint32_t i = threadIdx.x; i < m; i += FR_THREADS) sk[i] = keys[base + i];
+	__syncthreads();
+	fr_bitonic(sk, m, threadIdx.x);
+	for (uint32_t i = threadIdx.x; i < m; i += FR_THREADS) keys[base + i] = sk[i];
+}
+
+// one global stage: flip (i <-> i ^ (k-1)) or half-cleaner (i <-> i + j)
+__global__ __launch_bounds__(FR_THREADS) void k_bitonic_global(uint64_t* __restrict__ keys, uint32_t n, uint32_t half_pairs,
+                                                               uint32_t k, uint32_t j)
+{
+	const uint32_t t = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (t >= half_pairs) return;
+	uint32_t i, l;
+	if (j == 0) { const uint32_t half = k >> 1; i = ((t / half) * k) + (t % half); l = i ^ (k - 1); }
+	else { i = ((t / j) * (j << 1)) + (t % j); l = i + j; }
+	if (l < n)
+	{
+		uint64_t a = keys[i], b = keys[l];
+		if (a > b) { keys[i] = b; keys[l] = a; }
+	}
+}
+
+// half-cleaner stages j = FR_KNN_CHUNK/2 .. 1 inside each chunk, in LDS
+__global__ __launch_bounds__(FR_THREADS) void k_bitonic_chunk_merge(uint64_t* __restrict__ keys, uint32_t n)
+{
+	__shared__ uint64_t sk[FR_KNN_CHUNK];
+	const uint32_t base = blockIdx.x * FR_KNN_CHUNK;
+	const uint32_t m = min((uint32_t)FR_KNN_CHUNK, n - base);
+	for (uint32_t i = threadIdx.x; i < m; i += FR_THREADS) sk[i] = keys[base + i];
+	__syncthreads();
+	for (uint32_t j = FR_KNN_CHUNK >> 1; j > 0; j >>= 1)
+	{
+		for (uint32_t t = threadIdx.x; t < (FR_KNN_CHUNK >> 1); t += FR_THREADS)
+		{
+			const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+			const uint32_t l = i + j;
+			if (l < m)
+			{
+				uint64_t a = sk[i], b = sk[l];
+				if (a > b) { sk[i] = b; sk[l] = a; }
+			}
+		}
+		__syncthreads();
+	}
+	for (uint32_t i = threadIdx.x; i < m; i += FR_THREADS) keys[base + i] = sk[i];
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_knn_gather(int P, const float* __restrict__ pts, const uint64_t* __restrict__ keys,
+                                                           float* __restrict__ sorted)
+{
+	int t = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (t >= P) return;
+	const uint32_t i = (uint32_t)keys[t];
+	sorted[3 * (size_t)t] = pts[3 * (size_t)i]; sorted[3 * (size_t)t + 1] = pts[3 * (size_t)i + 1]; sorted[3 * (size_t)t + 2] = pts[3 * (size_t)i + 2];
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_knn_boxes(int P, const float* __restrict__ sorted, float* __restrict__ boxes)
+{
+	__shared__ float red[6][4];
+	const int b = blockIdx.x;
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	const int end = min(P, (b + 1) * FR_KNN_BOX);
+	for (int t = b * FR_KNN_BOX + threadIdx.x; t < end; t += FR_THREADS)
+#pragma unroll
+		for (int a = 0; a < 3; a++) { float x = sorted[3 * (size_t)t + a]; lo[a] = fminf(lo[a], x); hi[a] = fmaxf(hi[a], x); }
+#pragma unroll
+	for (int a = 0; a < 3; a++)
+	{
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+		if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 6)
+	{
+		const int a = threadIdx.x;
+		float r = red[a][0];
+		for (int w = 1; w < 4; w++) r = a < 3 ? fminf(r, red[a][w]) : fmaxf(r, red[a][w]);
+		boxes[6 * (size_t)b + a] = r;
+	}
+}
+
+__device__ __forceinline__ void fr_knn_update(float px, float py, float pz, float qx, float qy, float qz, float* best)
+{
+	const float dx = qx - px, dy = qy - py, dz = qz - pz;
+	float dist = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+	for (int j = 0; j < 3; j++)
+		if (best[j] > dist) { float t = best[j]; best[j] = dist; dist = t; }
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_knn_search(int P, const float* __restrict__ sorted, const uint64_t* __restrict__ keys,
+                                                           const float* __restrict__ boxes, int nb, float* __restrict__ out)
+{
+	const int t = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (t >= P) return;
+	const float px = sorted[3 * (size_t)t], py = sorted[3 * (size_t)t + 1], pz = sorted[3 * (size_t)t + 2];
+	float best[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f };
+	for (int s = max(0, t - 3); s <= min(P - 1, t + 3); s++)
+	{
+		if (s == t) continue;
+		fr_knn_update(px, py, pz, sorted[3 * (size_t)s], sorted[3 * (size_t)s + 1], sorted[3 * (size_t)s + 2], best);
+	}
+	const float reject = best[2];
+	best[0] = best[1] = best[2] = 3.402823466e+38f;
+	for (int b = 0; b < nb; b++)
+	{
+		const float* bx = boxes + 6 * (size_t)b;
+		float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+		if (px < bx[0] || px > bx[3]) ddx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
+		if (py < bx[1] || py > bx[4]) ddy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
+		if (pz < bx[2] || pz > bx[5]) ddz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
+		const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
+		if (dist > reject || dist > best[2]) continue;
+		const int end = min(P, (b + 1) * FR_KNN_BOX);
+		for (int s = b * FR_KNN_BOX; s < end; s++)
+		{
+			if (s == t) continue;
+			fr_knn_update(px, py, pz, sorted[3 * (size_t)s], sorted[3 * (size_t)s + 1], sorted[3 * (size_t)s + 2], best);
+		}
+	}
+	out[(uint32_t)keys[t]] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+struct FrKnnLayout { size_t keys, sorted, boxes, mm, total; };
+static FrKnnLayout fr_knn_layout(int64_t P)
+{
+	FrKnnLayout L;
+	size_t o = 0;
+	const int64_t nb = (P + FR_KNN_BOX - 1) / FR_KNN_BOX;
+	L.keys = o; o = fr_align(o + (size_t)P * 8);
+	L.sorted = o; o = fr_align(o + (size_t)P * 12);
+	L.boxes = o; o = fr_align(o + (size_t)nb * 24);
+	L.mm = o; o = fr_align(o + 32);
+	L.total = o;
+	return L;
+}
+
+extern "C" size_t fr_knn_workspace_bytes(int32_t P)
+{
+	if (P < 0) return 0;
+	return fr_knn_layout(P).total;
+}
+
+extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, fr_stream_t stream)
+{
+	if (P < 0) return fr_fail(FR_EINVAL, "fr_knn_dist2: P < 0");
+	if (P == 0) return FR_OK;
+	if (!points || !out || !workspace) return fr_fail(FR_EINVAL, "fr_knn_dist2: null pointer");
+	FrKnnLayout L = fr_knn_layout(P);
+	if (workspace_bytes < L.total) return fr_fail(FR_ENOSPACE, "fr_knn_dist2: workspace smaller than fr_knn_workspace_bytes()");
+	hipStream_t s = (hipStream_t)stream;
+	char* ws = (char*)workspace;
+	uint64_t* keys = (uint64_t*)(ws + L.keys);
+	float* sorted = (float*)(ws + L.sorted);
+	float* boxes = (float*)(ws + L.boxes);
+	uint32_t* mm = (uint32_t*)(ws + L.mm);
+	int rc;
+	(void)hipMemsetAsync(mm, 0xFF, 12, s);
+	(void)hipMemsetAsync(mm + 3, 0x00, 12, s);
+	const int nblk = (P + FR_THREADS - 1) / FR_THREADS;
+	hipLaunchKernelGGL(k_knn_minmax, dim3(nblk < 1024 ? nblk : 1024), dim3(FR_THREADS), 0, s, P, points, mm);
+	if ((rc = fr_check_launch("k_knn_minmax"))) return rc;
+	hipLaunchKernelGGL(k_knn_morton, dim3(nblk), dim3(FR_THREADS), 0, s, P, points, mm, keys);
+	if ((rc = fr_check_launch("k_knn_morton"))) return rc;
+	// bitonic network over the whole array
+	const uint32_t n = (uint32_t)P;
+	uint32_t n_pad = 1;
+	while (n_pad < n) n_pad <<= 1;
+	const uint32_t nchunks = (n + FR_KNN_CHUNK - 1) / FR_KNN_CHUNK;
+	hipLaunchKernelGGL(k_bitonic_chunk_sort, dim3(nchunks), dim3(FR_THREADS), 0, s, keys, n);
+	if ((rc = fr_check_launch("k_bitonic_chunk_sort"))) return rc;
+	const uint32_t half_pairs = n_pad >> 1;
+	const uint32_t gblk = (half_pairs + FR_THREADS - 1) / FR_THREADS;
+	for (uint32_t k = FR_KNN_CHUNK << 1; k <= n_pad && k != 0; k <<= 1)
+	{
+		hipLaunchKernelGGL(k_bitonic_global, dim3(gblk), dim3(FR_THREADS), 0, s, keys, n, half_pairs, k, 0u);
+		for (uint32_t j = k >> 2; j >= FR_KNN_CHUNK; j >>= 1)
+			hipLaunchKernelGGL(k_bitonic_global, dim3(gblk), dim3(FR_THREADS), 0, s, keys, n, half_pairs, k, j);
+		hipLaunchKernelGGL(k_bitonic_chunk_merge, dim3(nchunks), dim3(FR_THREADS), 0, s, keys, n);
+	}
+	if ((rc = fr_check_launch("k_bitonic_global"))) return rc;
+	hipLaunchKernelGGL(k_knn_gather, dim3(nblk), dim3(FR_THREADS), 0, s, P, points, keys, sorted);
+	const int nb = (P + FR_KNN_BOX - 1) / FR_KNN_BOX;
+	hipLaunchKernelGGL(k_knn_boxes, dim3(nb), dim3(FR_THREADS), 0, s, P, sorted, boxes);
+	hipLaunchKernelGGL(k_knn_search, dim3(nblk), dim3(FR_THREADS), 0, s, P, sorted, keys, boxes, nb, out);
+	return fr_check_launch("k_knn_search");
+}

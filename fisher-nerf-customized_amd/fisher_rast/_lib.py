@@ -1,0 +1,127 @@
+"""ctypes binding of libfisher_rast.so (C ABI declared in include/fisher_rast.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There is no
+CPU fallback: if the shared object is missing, loading raises and every op of the package fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfisher_rast.so")
+
+FR_OK, FR_EINVAL, FR_ELAUNCH, FR_ENOSPACE = 0, 1, 2, 3
+
+_f32p = ctypes.c_void_p  # device pointers travel as raw addresses
+
+
+class RasterCfg(ctypes.Structure):
+    _fields_ = [
+        ("P", ctypes.c_int32),
+        ("image_height", ctypes.c_int32),
+        ("image_width", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float),
+        ("tanfovy", ctypes.c_float),
+        ("scale_modifier", ctypes.c_float),
+        ("sh_degree", ctypes.c_int32),
+        ("sh_coeffs", ctypes.c_int32),
+        ("prefiltered", ctypes.c_int32),
+        ("bg", _f32p),
+        ("viewmatrix", _f32p),
+        ("projmatrix", _f32p),
+        ("campos", _f32p),
+    ]
+
+
+class Gaussians(ctypes.Structure):
+    _fields_ = [
+        ("means3D", _f32p),
+        ("colors_precomp", _f32p),
+        ("shs", _f32p),
+        ("opacities", _f32p),
+        ("scales", _f32p),
+        ("rotations", _f32p),
+        ("cov3D_precomp", _f32p),
+    ]
+
+
+class FisherCfg(ctypes.Structure):
+    _fields_ = [
+        ("n_views", ctypes.c_int32),
+        ("columns", ctypes.c_int32),
+        ("dL_dpix", ctypes.c_float),
+        ("w2c", _f32p),
+        ("H_inv", _f32p),
+        ("H_inv_view_stride", ctypes.c_int64),
+        ("out_scores", _f32p),
+        ("out_H", _f32p),
+        ("out_H_view_stride", ctypes.c_int64),
+        ("out_vis_count", ctypes.c_void_p),
+        ("out_num_rendered", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/fisher_rast.h declares
+EXPORTS = (
+    "fr_version", "fr_last_error", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
+    "fr_forward", "fr_backward", "fr_fisher_workspace_bytes", "fr_fisher_views",
+    "fr_knn_workspace_bytes", "fr_knn_dist2",
+)
+
+_lib = None
+
+
+class FisherRastError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FisherRastError(
+            f"{SO_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root). "
+            "There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(SO_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise FisherRastError(f"{SO_PATH} does not export {name}")
+    lib.fr_version.restype = ctypes.c_int
+    lib.fr_last_error.restype = ctypes.c_char_p
+    lib.fr_workspace_bytes.restype = ctypes.c_int
+    lib.fr_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                       ctypes.POINTER(ctypes.c_size_t)]
+    lib.fr_workspace_layout.restype = ctypes.c_int
+    lib.fr_workspace_layout.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                        ctypes.POINTER(ctypes.c_size_t)]
+    lib.fr_mark_visible.restype = ctypes.c_int
+    lib.fr_mark_visible.argtypes = [ctypes.c_int32, _f32p, _f32p, _f32p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_forward.restype = ctypes.c_int
+    lib.fr_forward.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians),
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                               _f32p, _f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_backward.restype = ctypes.c_int
+    lib.fr_backward.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians), ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                _f32p, ctypes.c_int32] + [_f32p] * 9 + [ctypes.c_void_p]
+    lib.fr_fisher_workspace_bytes.restype = ctypes.c_size_t
+    lib.fr_fisher_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int64]
+    lib.fr_fisher_views.restype = ctypes.c_int
+    lib.fr_fisher_views.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians),
+                                    ctypes.POINTER(FisherCfg), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64,
+                                    ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_knn_workspace_bytes.restype = ctypes.c_size_t
+    lib.fr_knn_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.fr_knn_dist2.restype = ctypes.c_int
+    lib.fr_knn_dist2.argtypes = [ctypes.c_int32, _f32p, _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != FR_OK:
+        msg = load().fr_last_error().decode("utf-8", "replace")
+        raise FisherRastError(f"{what} failed (code {rc}): {msg}")

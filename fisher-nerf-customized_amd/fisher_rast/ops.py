@@ -1,0 +1,331 @@
+"""Torch-tensor front end of the C ABI: device memory, streams and nothing else.
+
+Three groups of entry points:
+  * `rasterize_forward` / `rasterize_backward` / `mark_visible` -- the argument lists of the reference's
+    pybind module `_C` (thirdparty/diff-gaussian-rasterization-modified/ext.cpp:14-18,
+    rasterize_points.h:18-66); `diff_gaussian_rasterization/_C.py` re-exports them under the reference names.
+  * `FisherScorer` -- the batched multi-view scorer behind GaussianSLAM.compute_Hessian / compute_H_train /
+    pose_eval (models/SLAM/gaussian.py:1338-1375, 1503-1570).
+  * `knn_dist2` -- simple_knn._C.distCUDA2.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import FisherRastError, RasterCfg, Gaussians, FisherCfg
+
+
+def _need_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise FisherRastError(f"{name} must live on a HIP device; fisher_rast has no CPU path")
+
+
+def _prep(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    """contiguous fp32 on `device`; the reference's empty tensors (any device) become None -> null pointer."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _raster_cfg(P, H, W, tanfovx, tanfovy, scale_modifier, degree, M, prefiltered, bg, view, proj, campos):
+    c = RasterCfg()
+    c.P, c.image_height, c.image_width = int(P), int(H), int(W)
+    c.tanfovx, c.tanfovy, c.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
+    c.sh_degree, c.sh_coeffs, c.prefiltered = int(degree), int(M), int(bool(prefiltered))
+    c.bg, c.viewmatrix, c.projmatrix, c.campos = _ptr(bg), _ptr(view), _ptr(proj), _ptr(campos)
+    return c
+
+
+def _gaussians(means3D, colors, sh, opacity, scales, rotations, cov3D):
+    g = Gaussians()
+    g.means3D, g.colors_precomp, g.shs = _ptr(means3D), _ptr(colors), _ptr(sh)
+    g.opacities, g.scales, g.rotations, g.cov3D_precomp = _ptr(opacity), _ptr(scales), _ptr(rotations), _ptr(cov3D)
+    return g
+
+
+def workspace_bytes(P, W, H, max_rendered):
+    out = (ctypes.c_size_t * 3)()
+    _lib.check(_lib.load().fr_workspace_bytes(P, W, H, max_rendered, out), "fr_workspace_bytes")
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def workspace_layout(P, W, H, max_rendered):
+    names = ("depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped",
+             "tile_count", "tile_offset", "tile_fill", "final_T", "n_contrib", "status", "keys")
+    out = (ctypes.c_size_t * 13)()
+    _lib.check(_lib.load().fr_workspace_layout(P, W, H, max_rendered, out), "fr_workspace_layout")
+    return {n: int(out[i]) for i, n in enumerate(names)}
+
+
+# high-water mark of tile instances per device, so that the binning buffer is normally large enough first time
+_capacity_hint = {}
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:198-217)."""
+    _need_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m, v, pr = _prep(means3D, dev), _prep(viewmatrix, dev), _prep(projmatrix, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().fr_mark_visible(P, _ptr(m), _ptr(v), _ptr(pr), ctypes.c_void_p(present.data_ptr()),
+                                                   _stream(dev)), "fr_mark_visible")
+    return present
+
+
+def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                      viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                      prefiltered):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115): returns
+    (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer, depth[1,H,W])."""
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _need_gpu(means3D, "means3D")
+    dev = means3D.device
+    lib = _lib.load()
+    P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+    means3D = _prep(means3D, dev)
+    colors, sh_t = _prep(colors, dev), _prep(sh, dev)
+    opacity, scales, rotations, cov3D_precomp = (_prep(opacity, dev), _prep(scales, dev), _prep(rotations, dev),
+                                                 _prep(cov3D_precomp, dev))
+    bg, view, proj, cpos = _prep(background, dev), _prep(viewmatrix, dev), _prep(projmatrix, dev), _prep(campos, dev)
+    M = int(sh.shape[1]) if (sh is not None and sh.numel() != 0) else 0
+
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    status = torch.zeros((4,), dtype=torch.int32, device=dev)
+    cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, prefiltered, bg, view, proj, cpos)
+    g = _gaussians(means3D, colors, sh_t, opacity, scales, rotations, cov3D_precomp)
+
+    key = (dev.index, P, H, W)
+    capacity = max(_capacity_hint.get(key, 0), 2 * P, 1 << 16)
+    with torch.cuda.device(dev):
+        while True:
+            gb, bb, ib = workspace_bytes(P, W, H, capacity)
+            geom = torch.empty((gb,), dtype=torch.uint8, device=dev)
+            binning = torch.empty((bb,), dtype=torch.uint8, device=dev)
+            img = torch.empty((ib,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.fr_forward(ctypes.byref(cfg), ctypes.byref(g), geom.data_ptr(), binning.data_ptr(), capacity,
+                                      img.data_ptr(), _ptr(out_color), _ptr(out_depth), radii.data_ptr(),
+                                      status.data_ptr(), _stream(dev)), "fr_forward")
+            # same host synchronisation as the reference (rasterizer_impl.cu:282: cudaMemcpy of num_rendered)
+            st = status.cpu()
+            num_rendered = int(st[0])
+            if int(st[1]) == 0:
+                break
+            capacity = int(num_rendered * 1.25) + 1024
+    _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(num_rendered * 1.25) + 1024)
+    return num_rendered, out_color, radii, geom, binning, img, out_depth
+
+
+def rasterize_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                       viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer,
+                       R, binningBuffer, imageBuffer, power, opacities=None):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196): returns
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    _need_gpu(means3D, "means3D")
+    dev = means3D.device
+    lib = _lib.load()
+    P = int(means3D.shape[0])
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    M = int(sh.shape[1]) if (sh is not None and sh.numel() != 0) else 0
+    means3D = _prep(means3D, dev)
+    colors, sh_t = _prep(colors, dev), _prep(sh, dev)
+    scales, rotations, cov3D_precomp = _prep(scales, dev), _prep(rotations, dev), _prep(cov3D_precomp, dev)
+    bg, view, proj, cpos = _prep(background, dev), _prep(viewmatrix, dev), _prep(projmatrix, dev), _prep(campos, dev)
+    dL = _prep(dL_dout_color, dev)
+
+    def new(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = new(P, 3), new(P, 3), new(P, 3)
+    dL_dconic, dL_dopacity, dL_dcov3D = new(P, 2, 2), new(P, 1), new(P, 6)
+    dL_dsh, dL_dscales, dL_drotations = torch.zeros((P, M, 3), dtype=torch.float32, device=dev), new(P, 3), new(P, 4)
+    if P != 0:
+        # the kernels read opacity from the conic_opacity records of the geometry buffer; the pointer below only has
+        # to be non-null for argument validation
+        opac = _prep(opacities, dev) if opacities is not None else means3D
+        cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, False, bg, view, proj, cpos)
+        g = _gaussians(means3D, colors, sh_t, opac, scales, rotations, cov3D_precomp)
+        with torch.cuda.device(dev):
+            _lib.check(lib.fr_backward(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
+                                       binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), int(power),
+                                       _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D),
+                                       _ptr(dL_dcov3D), _ptr(dL_dsh) if M > 0 else None, _ptr(dL_dscales),
+                                       _ptr(dL_drotations), _ptr(dL_dconic), _stream(dev)), "fr_backward")
+    else:
+        for t in (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations):
+            t.zero_()
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+class FisherScorer:
+    """Batched Fisher-information scorer for one Gaussian map and one camera.
+
+    Holds the activated render variables (what gaussian.py:1529-1543 builds per call) and a reusable
+    workspace.  `run()` scores / accumulates any number of views with no host synchronisation; the caller
+    synchronises when it reads the results.  Overflow of the tile-instance buffer is detected from the
+    device status word when results are fetched (`fetch`), and the batch is re-run with a larger buffer.
+    """
+
+    WORKSPACE_BUDGET = 6 << 30  # bytes of dense per-view geometry before views are processed in chunks
+
+    def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
+                 dL_dpix: float = 1e-3):
+        _need_gpu(means3D, "means3D")
+        if columns not in (4, 11):
+            raise ValueError("columns must be 4 or 11")
+        self.lib = _lib.load()
+        self.dev = means3D.device
+        self.rs = raster_settings
+        self.columns = columns
+        self.dL = float(dL_dpix)
+        d = self.dev
+        self.means3D, self.colors = _prep(means3D.detach(), d), _prep(rgb_colors.detach(), d)
+        self.rotations, self.opacities = _prep(rotations.detach(), d), _prep(opacities.detach().reshape(-1), d)
+        scales = scales.detach()
+        if scales.dim() == 2 and scales.shape[-1] == 1:  # isotropic (gaussian.py:1532-1533)
+            scales = torch.tile(scales, (1, 3))
+        self.scales = _prep(scales, d)
+        self.P = int(self.means3D.shape[0])
+        self.H, self.W = int(raster_settings.image_height), int(raster_settings.image_width)
+        self.bg = _prep(raster_settings.bg, d)
+        self.view = _prep(raster_settings.viewmatrix, d)
+        self.proj = _prep(raster_settings.projmatrix, d)
+        self.campos = _prep(raster_settings.campos, d)
+        self._ws = None
+        self._ws_key = None
+        self.per_view_capacity = max(self.P, 1 << 16)
+        self.cfg = _raster_cfg(self.P, self.H, self.W, raster_settings.tanfovx, raster_settings.tanfovy,
+                               raster_settings.scale_modifier, raster_settings.sh_degree, 0,
+                               raster_settings.prefiltered, self.bg, self.view, self.proj, self.campos)
+        self.g = _gaussians(self.means3D, self.colors, None, self.opacities, self.scales, self.rotations, None)
+
+    # -- helpers -------------------------------------------------------------------------------------
+    def max_views_per_launch(self):
+        per_view = max(self.P, 1) * 32 + self.per_view_capacity * 8
+        return max(1, int(self.WORKSPACE_BUDGET // per_view))
+
+    def _workspace(self, V, max_rendered):
+        key = (V, max_rendered)
+        if self._ws is None or self._ws_key != key:
+            nbytes = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, V, max_rendered))
+            if nbytes == 0:
+                raise FisherRastError("fr_fisher_workspace_bytes: bad argument")
+            if self._ws is None or self._ws.numel() < nbytes:
+                self._ws = None
+                self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+            self._ws_key = key
+        return self._ws
+
+    def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False):
+        """Enqueue one batch (no sync).  w2c: [V,4,4] world->camera on the device.
+        Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4]."""
+        d = self.dev
+        w2c = _prep(w2c.reshape(-1, 4, 4), d)
+        V = int(w2c.shape[0])
+        C = self.columns
+        max_rendered = V * self.per_view_capacity
+        ws = self._workspace(V, max_rendered)
+        fc = FisherCfg()
+        fc.n_views, fc.columns, fc.dL_dpix = V, C, self.dL
+        fc.w2c = _ptr(w2c)
+        scores = None
+        if H_inv is not None:
+            H_inv = _prep(H_inv, d)
+            want = (V * self.P * C) if H_inv_per_view else (self.P * C)
+            if H_inv.numel() != want:
+                raise ValueError(f"H_inv has {H_inv.numel()} elements, expected {want}")
+            fc.H_inv = _ptr(H_inv)
+            fc.H_inv_view_stride = self.P * C if H_inv_per_view else 0
+            scores = torch.zeros((V,), dtype=torch.float32, device=d)
+            fc.out_scores = _ptr(scores)
+        if out_H is not None:
+            want = (V * self.P * C) if out_H_per_view else (self.P * C)
+            if out_H.numel() != want or out_H.dtype != torch.float32 or not out_H.is_contiguous() or out_H.device != d:
+                raise ValueError("out_H must be a contiguous fp32 device tensor of [V,]P*columns elements")
+            fc.out_H = _ptr(out_H)
+            fc.out_H_view_stride = self.P * C if out_H_per_view else 0
+        vis = torch.zeros((V,), dtype=torch.int32, device=d)
+        nr = torch.zeros((V,), dtype=torch.int32, device=d)
+        status = torch.zeros((4,), dtype=torch.int32, device=d)
+        fc.out_vis_count = vis.data_ptr()
+        fc.out_num_rendered = nr.data_ptr()
+        with torch.cuda.device(d):
+            _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
+                                                ws.data_ptr(), ws.numel(), max_rendered, status.data_ptr(),
+                                                _stream(d)), "fr_fisher_views")
+        return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv))
+
+    def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False):
+        """launch() + overflow handling.  Synchronises once (to read the 16-byte status word)."""
+        w2c = w2c.reshape(-1, 4, 4)
+        V = int(w2c.shape[0])
+        chunk = self.max_views_per_launch()
+        outs = []
+        v0 = 0
+        while v0 < V:
+            v1 = min(V, v0 + chunk)
+            hi = H_inv
+            if H_inv is not None and H_inv_per_view:
+                hi = H_inv.reshape(V, -1)[v0:v1]
+            oh = out_H
+            if out_H is not None and out_H_per_view:
+                oh = out_H.view(V, -1)[v0:v1]
+            snapshot = oh.clone() if oh is not None else None
+            while True:
+                r = self.launch(w2c[v0:v1], hi, H_inv_per_view, oh, out_H_per_view)
+                st = r["status"].cpu()
+                if int(st[1]) == 0:
+                    break
+                # tile-instance buffer too small: nothing was scored or accumulated; grow and redo this chunk
+                if snapshot is not None:
+                    oh.copy_(snapshot)
+                self.per_view_capacity = int(int(st[0]) * 1.25 / (v1 - v0)) + 4096
+                chunk = min(chunk, self.max_views_per_launch())
+                if v1 - v0 > chunk:
+                    v1 = v0 + chunk
+                    if H_inv is not None and H_inv_per_view:
+                        hi = H_inv.reshape(V, -1)[v0:v1]
+                    if out_H is not None and out_H_per_view:
+                        oh = out_H.view(V, -1)[v0:v1]
+                        snapshot = oh.clone()
+            outs.append(r)
+            v0 = v1
+        res = dict(vis_count=torch.cat([o["vis_count"] for o in outs]),
+                   num_rendered=torch.cat([o["num_rendered"] for o in outs]))
+        res["scores"] = torch.cat([o["scores"] for o in outs]) if H_inv is not None else None
+        return res
+
+
+def knn_dist2(points: torch.Tensor) -> torch.Tensor:
+    """simple_knn._C.distCUDA2: mean squared distance to the 3 nearest other points, [P,3] -> [P]."""
+    _need_gpu(points, "points")
+    dev = points.device
+    lib = _lib.load()
+    pts = _prep(points, dev)
+    P = int(pts.shape[0]) if pts is not None else 0
+    out = torch.zeros((P,), dtype=torch.float32, device=dev)
+    if P == 0:
+        return out
+    nbytes = int(lib.fr_knn_workspace_bytes(P))
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.fr_knn_dist2(P, _ptr(pts), _ptr(out), ws.data_ptr(), ws.numel(), _stream(dev)), "fr_knn_dist2")
+    return out

@@ -1,0 +1,220 @@
+"""`GaussianSLAM`: the Fisher-information / render operator surface of the reference class
+(models/SLAM/gaussian.py) on MI355X.
+
+In scope (same names, arguments and return conventions as the reference):
+    compute_Hessian (1503-1570)   compute_H_train (1338-1348)   pose_eval (1354-1375)
+    render_at_pose (555-579)      gs_pts_cnt (1350-1352)        gaussian_points / cur_frame_idx (1590-1598)
+    pause / resume / color_refinement / stop (1600-1614)
+The SLAM loop itself (init, track_rgbd, densify, keyframe selection ...) is NOT rebuilt: it is reference
+Python that stays as it is.  `FisherOps.install(cls)` grafts the accelerated methods onto the reference class
+so that tester_gaussians_navigation.py keeps calling `slam.pose_eval(...)` unchanged; `GaussianSLAM` below is
+the same operator surface as a standalone object built from a parameter dict (a `params{t}.npz` checkpoint
+or synthetic data) for tests and benchmarks.
+
+What changes underneath: instead of one rasteriser forward + backward(power=2) + cat + sum per view, with
+per-view allocations and two host syncs, every call batches its views through FisherScorer
+(fisher_rast/ops.py -> fr_fisher_views) and synchronises once when the scores are brought to the host.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+from fisher_rast.ops import FisherScorer
+from models.SLAM.utils.recon_helpers import setup_camera
+from models.SLAM.utils.slam_helpers import transformed_params2rendervar, transformed_params2depthplussilhouette
+
+
+class FisherOps:
+    """Mixin with the accelerated Fisher methods.  Needs: self.params (dict of tensors), self.cam
+    (GaussianRasterizationSettings), self.keyframe_list (dicts with 'est_w2c')."""
+
+    FISHER_COLUMNS = 4       # [camera-frame mean xyz | opacity]
+    H_TRAIN_REG = 0.1        # gaussian.py:1357
+
+    # -- internals -----------------------------------------------------------------------------------
+    def _device(self):
+        return self.params['means3D'].device
+
+    def _as_w2c(self, m):
+        if isinstance(m, np.ndarray):
+            m = torch.from_numpy(m)
+        return m.to(self._device()).float()
+
+    def _scorer(self, extra=None):
+        """Activated render variables (gaussian.py:1529-1533) wrapped in a FisherScorer.  Rebuilt on every public
+        call because the map changes between planning rounds; `extra` appends random Gaussians
+        (gaussian_object.py:1971-1992)."""
+        p = self.params
+        with torch.no_grad():
+            means = p['means3D'].detach()
+            colors = p['rgb_colors'].detach() if p.get('rgb_colors', None) is not None else \
+                torch.full_like(means, 0.5)
+            rot = F.normalize(p['unnorm_rotations'].detach())
+            op = torch.sigmoid(p['logit_opacities'].detach())
+            sc = torch.exp(p['log_scales'].detach())
+            if sc.shape[-1] == 1:
+                sc = torch.tile(sc, (1, 3))
+            if extra is not None and extra is not False:
+                dev = means.device
+                means = torch.cat([means, extra['means3D'].to(dev).float()], dim=0)
+                rot = torch.cat([rot, extra['rotations'].to(dev).float()], dim=0)
+                op = torch.cat([op, extra['opacity'].to(dev).float().reshape(-1, 1)], dim=0)
+                sc = torch.cat([sc, extra['scales'].to(dev).float()], dim=0)
+                colors = torch.cat([colors, torch.full((extra['means3D'].shape[0], 3), 0.5, device=dev)], dim=0)
+        return FisherScorer(self.cam, means, colors, rot, op, sc, columns=self.FISHER_COLUMNS, dL_dpix=1e-3)
+
+    # -- reference surface ---------------------------------------------------------------------------
+    def compute_Hessian(self, rel_w2c, return_points=False, random_gaussian_params=False, return_pose=False):
+        """One view's diagonal Fisher proxy (gaussian.py:1503-1570): (N, C) if return_points else flat
+        [means(3N) | opacity(N)] -- the reference flattens per block, not per row (1559-1560)."""
+        scorer = self._scorer(random_gaussian_params if self.FISHER_COLUMNS == 11 else None)
+        w2c = self._as_w2c(rel_w2c).reshape(1, 4, 4)
+        N, C = scorer.P, self.FISHER_COLUMNS
+        cur_H = torch.zeros((N, C), dtype=torch.float32, device=self._device())
+        res = scorer.run(w2c, out_H=cur_H)
+        self._last_vis_count = res["vis_count"]
+        if not return_points:
+            blocks = [cur_H[:, 0:3].reshape(-1), cur_H[:, 3:4].reshape(-1)]
+            if C == 11:
+                blocks += [cur_H[:, 4:7].reshape(-1), cur_H[:, 7:11].reshape(-1)]
+            cur_H = torch.cat(blocks)
+        if not return_pose:
+            return cur_H
+        pose_H = torch.eye(6, device=self._device())
+        if C == 11:
+            return cur_H, pose_H, int(self._last_vis_count[0].item())
+        return cur_H, pose_H
+
+    def compute_H_train(self, random_gaussians=None):
+        """Sum of cur_H over the keyframes (gaussian.py:1338-1348), all keyframes in one batched call."""
+        if len(self.keyframe_list) == 0:
+            return None
+        scorer = self._scorer(random_gaussians if self.FISHER_COLUMNS == 11 else None)
+        w2cs = torch.stack([self._as_w2c(kf['est_w2c']) for kf in self.keyframe_list])
+        H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
+        scorer.run(w2cs, out_H=H_train)
+        return H_train
+
+    def gs_pts_cnt(self, random_gaussian_params=None):
+        """ API Setting """
+        return 1
+
+    def pose_eval(self, poses, random_gaussian_params=None, criterion=None):
+        """Scores of candidate poses (gaussian.py:1354-1375): returns (scores cpu fp32 [V], stack(c2w) [V,4,4])."""
+        extra = random_gaussian_params if self.FISHER_COLUMNS == 11 else None
+        H_train = self.compute_H_train(extra)
+        H_train_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
+        c2ws = [self._as_w2c(c2w) for c2w in poses]
+        c2w = torch.stack(c2ws)
+        w2c = torch.linalg.inv(c2w)
+        scorer = self._scorer(extra)
+        res = scorer.run(w2c, H_inv=H_train_inv)
+        scores = res["scores"].cpu()
+        return scores, c2w
+
+    def path_scores(self, w2cs, H_inv_per_view):
+        """Batched form of the planner's per-step `sum(cur_H * H_train_inv_path)` (tester 1688-1695): every view
+        gets its own weight block.  Returns the V sums on the device (the caller takes the log)."""
+        scorer = self._scorer()
+        return scorer.run(self._as_w2c(w2cs), H_inv=H_inv_per_view, H_inv_per_view=True)["scores"]
+
+    @classmethod
+    def install(cls, target_cls):
+        """Graft the accelerated methods onto the reference's class."""
+        for name in ("_device", "_as_w2c", "_scorer", "compute_Hessian", "compute_H_train", "pose_eval", "path_scores"):
+            setattr(target_cls, name, getattr(cls, name))
+        if not hasattr(target_cls, "FISHER_COLUMNS"):
+            target_cls.FISHER_COLUMNS = cls.FISHER_COLUMNS
+        target_cls.H_TRAIN_REG = cls.H_TRAIN_REG
+        return target_cls
+
+
+class GaussianSLAM(FisherOps):
+    """Standalone carrier of the operator surface: a Gaussian map (param dict), a camera and keyframes."""
+
+    def __init__(self, config=None, params=None, intrinsics=None, width=None, height=None, device="cuda"):
+        self.config = config
+        self.cfg = config
+        if config is not None and intrinsics is None:
+            cal = config["SLAM"]["Dataset"]["Calibration"] if "SLAM" in config else config["Dataset"]["Calibration"]
+            intrinsics = np.array([[cal["fx"], 0.0, cal["cx"]], [0.0, cal["fy"], cal["cy"]], [0.0, 0.0, 1.0]])
+            width = width or cal.get("width", None)
+            height = height or cal.get("height", None)
+        self.device = torch.device(device)
+        self.intrinsics = None if intrinsics is None else torch.as_tensor(np.asarray(intrinsics)).float().to(self.device)
+        self.params = {}
+        self.variables = {}
+        self.cam = None
+        self.frame_idx = 0
+        self.keyframe_list = []
+        self.keyframe_time_indices = []
+        self.first_frame_w2c = torch.eye(4, device=self.device)
+        self.save_dir = self.eval_dir = None
+        if params is not None:
+            self.load_params(params)
+        if intrinsics is not None and width is not None and height is not None:
+            self.set_camera(width, height, intrinsics)
+
+    # -- construction helpers (checkpoint format: common_utils.py:45-59, gaussian.py:156-168) ----------
+    def load_params(self, params):
+        if isinstance(params, str):
+            params = dict(np.load(params))
+        self.params = {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).float().to(self.device)
+                       for k, v in params.items()}
+        return self
+
+    def set_camera(self, width, height, intrinsics):
+        k = np.asarray(intrinsics.cpu() if isinstance(intrinsics, torch.Tensor) else intrinsics)
+        self.intrinsics = torch.as_tensor(k).float().to(self.device)
+        # the view matrix is identity: Gaussians are moved into the candidate frame instead (gaussian.py:493-495)
+        self.cam = setup_camera(width, height, k, np.eye(4), device=self.device)
+        return self
+
+    def add_keyframe(self, est_w2c, **extra):
+        kf = dict(est_w2c=self._as_w2c(est_w2c), id=len(self.keyframe_list))
+        kf.update(extra)
+        self.keyframe_list.append(kf)
+        return kf
+
+    # -- rendering (gaussian.py:555-579) ---------------------------------------------------------------
+    def render_at_pose(self, c2w, white_bg=True, mask=None):
+        rel_w2c = torch.linalg.inv(self._as_w2c(c2w))
+        pts = self.params['means3D']
+        pts4 = torch.cat((pts, torch.ones_like(pts[:, :1])), dim=1)
+        transformed_pts = (rel_w2c @ pts4.T).T[:, :3]
+        rendervar = transformed_params2rendervar(self.params, transformed_pts)
+        depth_sil_rendervar = transformed_params2depthplussilhouette(self.params, self.first_frame_w2c, transformed_pts)
+        im, radius, _, = Renderer(raster_settings=self.cam)(**rendervar)
+        self.variables['means2D'] = rendervar['means2D']
+        depth_sil, _, _, = Renderer(raster_settings=self.cam)(**depth_sil_rendervar)
+        depth = depth_sil[0, :, :].unsqueeze(0)
+        return {"render": im, "depth": depth}
+
+    # -- small surface ---------------------------------------------------------------------------------
+    @property
+    def cur_frame_idx(self):
+        return self.frame_idx
+
+    def get_gaussian_xyz(self):
+        return self.params['means3D']
+
+    @property
+    def gaussian_points(self):
+        return self.get_gaussian_xyz()
+
+    def pause(self):
+        """ API to be compatible with Mono GS """
+        return
+
+    def resume(self):
+        """ API to be compatible with Mono GS """
+        return
+
+    def color_refinement(self):
+        """ API to be compatible with Mono GS """
+        return
+
+    def stop(self):
+        """ API to be compatible with Mono GS """
+        return

@@ -1,0 +1,161 @@
+/*
+ * fisher_rast.h -- C ABI of libfisher_rast.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of davidea97/Fisher-Nerf-customized: the differentiable
+ * 3D-Gaussian-splat rasteriser with the FisherRF `grad_power` backward, the per-candidate-view
+ * Fisher-information scorer built on it, and simple-knn's distCUDA2.
+ *
+ * Every entry point
+ *   - takes plain device pointers and sizes (no torch types), plus an explicit HIP stream;
+ *   - never allocates, never synchronises the device, never throws;
+ *   - returns 0 on success or an FR_E* code; fr_last_error() gives the message (thread-local).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree,
+ * RAST = thirdparty/diff-gaussian-rasterization-modified):
+ *   fr_mark_visible      <- markVisible                    RAST/rasterize_points.cu:198-217,
+ *                                                          RAST/cuda_rasterizer/rasterizer_impl.cu:141-153
+ *   fr_forward           <- RasterizeGaussiansCUDA         RAST/rasterize_points.cu:35-115
+ *                           -> Rasterizer::forward         RAST/cuda_rasterizer/rasterizer_impl.cu:198-339
+ *   fr_backward          <- RasterizeGaussiansBackwardCUDA RAST/rasterize_points.cu:117-196
+ *                           -> Rasterizer::backward        RAST/cuda_rasterizer/rasterizer_impl.cu:343-434
+ *   fr_fisher_views      <- the Python loop GaussianSLAM.pose_eval / compute_H_train / compute_Hessian
+ *                           models/SLAM/gaussian.py:1338-1375, 1503-1570 and
+ *                           models/SLAM/gaussian_object.py:1541-1551, 1591-1617, 1940-2045
+ *                           (V x [forward + backward(power=2) + cat + sum]) as one batched call
+ *   fr_knn_dist2         <- simple_knn._C.distCUDA2 (thirdparty/simple-knn, un-vendored submodule)
+ *
+ * The pybind module `_C` of the reference (RAST/ext.cpp:14-18) is re-created in Python on top of
+ * this ABI by fisher-nerf-customized_amd/diff_gaussian_rasterization/_C.py; see INTEGRATION.md.
+ */
+#ifndef FISHER_RAST_H_INCLUDED
+#define FISHER_RAST_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_VERSION 100
+
+enum {
+	FR_OK = 0,
+	FR_EINVAL = 1,      /* bad argument (null pointer, negative size, unsupported combination) */
+	FR_ELAUNCH = 2,     /* HIP runtime error at launch; message has hipGetErrorString */
+	FR_ENOSPACE = 3     /* workspace too small (host-visible sizes only) */
+};
+
+/* device-side status word written by the kernels (int32[4] = {num_rendered_total, overflow, max_tile_count, reserved}) */
+#define FR_STATUS_WORDS 4
+
+typedef void* fr_stream_t; /* hipStream_t */
+
+/* Camera / raster settings: GaussianRasterizationSettings, RAST/diff_gaussian_rasterization/__init__.py:140-151.
+ * bg / viewmatrix / projmatrix / campos stay DEVICE pointers, as in the reference (they are CUDA tensors there);
+ * viewmatrix and projmatrix are the 16 floats of the transposed tensors, i.e. column-major matrices. */
+typedef struct fr_raster_cfg {
+	int32_t P;
+	int32_t image_height;
+	int32_t image_width;
+	float tanfovx;
+	float tanfovy;
+	float scale_modifier;
+	int32_t sh_degree;   /* D */
+	int32_t sh_coeffs;   /* M = shs.size(1), 0 when colours are precomputed */
+	int32_t prefiltered; /* accepted for signature parity; the device trap of auxiliary.h:156-160 is not reproduced */
+	const float* bg;
+	const float* viewmatrix;
+	const float* projmatrix;
+	const float* campos;
+} fr_raster_cfg;
+
+/* Gaussian inputs; a null pointer stands for the reference's empty tensor. */
+typedef struct fr_gaussians {
+	const float* means3D;        /* [P,3] */
+	const float* colors_precomp; /* [P,3] or null */
+	const float* shs;            /* [P,M,3] or null */
+	const float* opacities;      /* [P] (or [P,1]) */
+	const float* scales;         /* [P,3] or null */
+	const float* rotations;      /* [P,4] or null */
+	const float* cov3D_precomp;  /* [P,6] or null */
+} fr_gaussians;
+
+int fr_version(void);
+const char* fr_last_error(void);
+
+/* ---- single-view rasteriser (the reference's _C.rasterize_gaussians / _backward / mark_visible) ---- */
+
+/* Bytes of the three opaque work buffers (geomBuffer, binningBuffer, imgBuffer of the reference).
+ * out[0] geometry (P), out[1] binning (max_rendered tile instances), out[2] image (W,H). */
+int fr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t out[3]);
+
+/* Byte offsets of the named sections inside the three buffers (for tests / debuggers).
+ * geom:    [0] depths f32[P], [1] means2D f32[P,2], [2] conic_opacity f32[P,4], [3] cov3D f32[P,6],
+ *          [4] rgb f32[P,3], [5] clamped u8[P,3]
+ * image:   [6] tile_count u32[T], [7] tile_offset u32[T], [8] tile_fill u32[T], [9] final_T f32[HW],
+ *          [10] n_contrib u32[HW], [11] status i32[4]
+ * binning: [12] keys u64[R]  (sorted per tile: (depth_bits << 32) | gaussian_index) */
+int fr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t offsets[13]);
+
+int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    uint8_t* present, fr_stream_t stream);
+
+/* Forward.  binning_capacity = number of tile instances binning_ws can hold.  status (device int32[4]) receives
+ * {num_rendered, overflow}; when num_rendered > binning_capacity nothing is rendered, overflow = 1 and the caller
+ * re-runs with a larger buffer (the reference instead synchronises on num_rendered before sizing the buffer,
+ * rasterizer_impl.cu:282-286).  out_color [3,H,W], out_depth [1,H,W], radii [P]. */
+int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,
+               void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
+               float* out_color, float* out_depth, int32_t* radii, int32_t* status, fr_stream_t stream);
+
+/* Backward.  All nine gradient buffers are overwritten (zero-filled first, rasterize_points.cu:151-159).
+ * dL_dmeans2D [P,3], dL_dcolors [P,3], dL_dopacity [P,1], dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3]
+ * (may be null when M == 0), dL_dscales [P,3], dL_drotations [P,4], dL_dconic [P,2,2].
+ * power is the reference's `backward_power` (1 = gradients, 2 = squared per-pixel gradients). */
+int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                const void* geom_ws, const void* binning_ws, const void* image_ws,
+                const float* dL_dout_color, int32_t power,
+                float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
+                float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
+                fr_stream_t stream);
+
+/* ---- fused multi-view Fisher scorer -------------------------------------------------------------- */
+
+typedef struct fr_fisher_cfg {
+	int32_t n_views;
+	int32_t columns;            /* 4 = [mean_cam xyz | opacity] (gaussian.py:1555-1556);
+	                               11 = + [scale xyz | rot rxyz] (gaussian_object.py:2022-2027) */
+	float dL_dpix;              /* constant upstream gradient of every pixel/channel (reference: 1e-3) */
+	const float* w2c;           /* device [n_views,16], row-major 4x4 world->camera (rel_w2c) */
+	const float* H_inv;         /* device [P,columns] weights, or null */
+	int64_t H_inv_view_stride;  /* elements between consecutive views' H_inv blocks (0 = one block shared) */
+	float* out_scores;          /* device [n_views]: sum(cur_H * H_inv) per view, or null */
+	float* out_H;               /* device [.., P, columns], ACCUMULATED into (caller zero-fills), or null */
+	int64_t out_H_view_stride;  /* elements between views' blocks in out_H (0 = all views sum into one block) */
+	int32_t* out_vis_count;     /* device [n_views]: #Gaussians with radius > 0, or null */
+	int32_t* out_num_rendered;  /* device [n_views]: tile instances per view, or null */
+} fr_fisher_cfg;
+
+size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered);
+
+/* Scores n_views candidate poses in one batched launch sequence.  g->means3D are WORLD positions; each view's
+ * camera-frame means are computed in-kernel from cfg_f->w2c and then rendered through cfg->viewmatrix/projmatrix
+ * exactly as the reference does (gaussian.py:1523-1548; its camera has viewmatrix = I).
+ * status (device int32[4]) receives {total tile instances, overflow}; on overflow (total > max_rendered) no
+ * score is written. */
+int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, const fr_fisher_cfg* cfg_f,
+                    void* workspace, size_t workspace_bytes, int64_t max_rendered,
+                    int32_t* status, fr_stream_t stream);
+
+/* ---- simple-knn ---------------------------------------------------------------------------------- */
+
+size_t fr_knn_workspace_bytes(int32_t P);
+/* out[i] = mean of the squared distances from points[i] to its 3 nearest other points. */
+int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
+                 fr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHER_RAST_H_INCLUDED */

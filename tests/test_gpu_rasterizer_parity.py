@@ -1,0 +1,183 @@
+"""-m gpu: the HIP rasteriser (through the C ABI) against the oracle on identical inputs.
+Bar (north star): tile / sort indices bit-exact; RGB and gradients within 1e-4 relative.  The forward arithmetic
+is written to round exactly like the oracle, so the forward outputs are additionally required to be BIT-EXACT."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import hip_forward, hip_backward, assert_close, to_dev
+from scenes import random_scene, intrinsics
+
+pytestmark = pytest.mark.gpu
+
+
+def _pose(yaw=0.3, t=(0.2, -0.1, 0.3)):
+    w2c = np.eye(4, dtype=np.float32)
+    c, s = np.cos(yaw), np.sin(yaw)
+    w2c[:3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+    w2c[:3, 3] = t
+    return w2c
+
+
+def _scene(case):
+    if case == "general":
+        W, H, P = 256, 256, 20000
+        sc = random_scene(P, 0, zmin=-0.5, zmax=8.0, spread=1.5, scale=0.04)
+        sc["means3D"][:40, 2] = np.random.default_rng(0).uniform(0.0011, 0.2, 40)   # appendix B.1: huge near splats
+        w2c = _pose()
+    elif case == "ragged":          # image not a multiple of 16 (B.5), non-square
+        W, H, P = 200, 120, 6000
+        sc = random_scene(P, 1, scale=0.06)
+        w2c = _pose(-0.2)
+    elif case == "crowded_tile":    # one tile holds > 4096 splats: multi-round LDS batches + the global-memory sort path
+        W, H, P = 64, 64, 9000
+        rng = np.random.default_rng(2)
+        sc = random_scene(P, 2, scale=0.01)
+        z = rng.uniform(1.0, 6.0, P).astype(np.float32)
+        sc["means3D"] = np.stack([rng.uniform(-0.02, 0.02, P) * z, rng.uniform(-0.02, 0.02, P) * z, z], 1).astype(np.float32)
+        sc["opacities"] = rng.uniform(0.002, 0.05, P).astype(np.float32)
+        w2c = np.eye(4, dtype=np.float32)
+    elif case == "ties":            # duplicated Gaussians: equal (tile, depth) keys keep index order (B.6)
+        W, H, P = 96, 96, 3000
+        sc = random_scene(1000, 3, scale=0.08)
+        sc = {k: np.concatenate([v, v, v]) for k, v in sc.items()}
+        w2c = np.eye(4, dtype=np.float32)
+    elif case == "opaque":          # alpha saturating at 0.99 and early termination (B.3, B.4)
+        W, H, P = 128, 128, 8000
+        sc = random_scene(P, 4, scale=0.15, opacity_mean=6.0)
+        w2c = np.eye(4, dtype=np.float32)
+    return W, H, sc, w2c
+
+
+CASES = ["general", "ragged", "crowded_tile", "ties", "opaque"]
+
+
+@pytest.fixture(scope="module")
+def runs(gpu, oracle):
+    cache = {}
+
+    def get(case):
+        if case not in cache:
+            W, H, sc, w2c = _scene(case)
+            cam = oracle.setup_camera(W, H, intrinsics(W, H), w2c)
+            args = dict(colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+            want = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], **args)
+            got = hip_forward(gpu, cam, sc["means3D"], sc["opacities"], **args)
+            cache[case] = (cam, sc, want, got)
+        return cache[case]
+    return get
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_bit_exact(runs, case):
+    cam, sc, want, got = runs(case)
+    vis = want["radii"] > 0
+    assert vis.sum() > 0
+    assert np.array_equal(got["radii"], want["radii"])
+    assert np.array_equal(bits(got["depths"][vis]), bits(want["depths"][vis]))
+    assert np.array_equal(bits(got["means2D"][vis]), bits(want["means2D"][vis]))
+    assert np.array_equal(bits(got["conic_opacity"][vis]), bits(want["conic_opacity"][vis]))
+    assert np.array_equal(bits(got["cov3D"][vis]), bits(want["cov3D"][vis]))
+    # binning: per-tile ranges and the depth-sorted id list, bit for bit
+    assert got["num_rendered"] == want["num_rendered"]
+    assert np.array_equal(got["ranges"], want["ranges"])
+    assert np.array_equal(got["point_list"], want["point_list"])
+    if case == "crowded_tile":
+        assert got["tile_count"].max() > 4096
+    # render
+    assert np.array_equal(got["n_contrib"], want["n_contrib"])
+    assert np.array_equal(bits(got["final_T"]), bits(want["final_T"]))
+    assert np.array_equal(bits(got["color"]), bits(want["color"]))
+    assert np.array_equal(bits(got["depth"]), bits(want["depth"]))
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("power", [1, 2])
+def test_backward_parity(runs, oracle, gpu, case, power):
+    cam, sc, want, got = runs(case)
+    H, W = cam.image_height, cam.image_width
+    rng = np.random.default_rng(5)
+    dL = rng.normal(size=(3, H, W)).astype(np.float32) if power == 1 else np.full((3, H, W), 1e-3, np.float32)
+    gw = oracle.rasterize_backward(cam, want, dL, power)
+    gg = hip_backward(gpu, cam, got, dL, power)
+    for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        # power 1 sums signed terms (cancellation): compare against the tensor's scale; power 2 sums squares: 1e-4 relative
+        if power == 2:
+            assert_close(gg[n], gw[n], 1e-4, f"{case}/{n}", atol_frac=1e-7)
+        else:
+            assert_close(gg[n], gw[n], 1e-4, f"{case}/{n}", atol_frac=2e-5)
+    assert gg["dL_dsh"].shape == (sc["means3D"].shape[0], 0, 3)
+
+
+def test_cov3d_precomp_path(gpu, oracle):
+    W, H, sc, w2c = _scene("ragged")
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), w2c)
+    base = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    cov = base["cov3D"].copy()
+    for i in np.nonzero(base["radii"] == 0)[0]:   # culled splats never had their covariance computed
+        cov[i] = [1e-3, 0, 0, 1e-3, 0, 1e-3]
+    want = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], cov3D_precomp=cov)
+    got = hip_forward(gpu, cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], cov3D_precomp=cov)
+    assert np.array_equal(got["radii"], want["radii"]) and np.array_equal(got["point_list"], want["point_list"])
+    assert np.array_equal(bits(got["color"]), bits(want["color"]))
+    dL = np.random.default_rng(1).normal(size=(3, H, W)).astype(np.float32)
+    gw = oracle.rasterize_backward(cam, want, dL, 1)
+    gg = hip_backward(gpu, cam, got, dL, 1)
+    for n in ("dL_dmeans3D", "dL_dcov3D", "dL_dopacity", "dL_dcolors"):
+        assert_close(gg[n], gw[n], 1e-4, n, atol_frac=2e-5)
+    assert np.all(gg["dL_dscales"] == 0) and np.all(gg["dL_drotations"] == 0)
+
+
+@pytest.mark.parametrize("deg", [0, 3])
+def test_sh_forward(gpu, oracle, deg):
+    W = H = 96
+    P = 3000
+    sc = random_scene(P, 9)
+    shs = np.random.default_rng(deg).normal(scale=0.4, size=(P, 16, 3)).astype(np.float32)
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), np.eye(4))._replace(sh_degree=deg, campos=np.array([0.1, -0.2, 0.05], np.float32))
+    want = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], shs=shs, scales=sc["scales"], rotations=sc["rotations"])
+    got = hip_forward(gpu, cam, sc["means3D"], sc["opacities"], shs=shs, scales=sc["scales"], rotations=sc["rotations"])
+    vis = want["radii"] > 0
+    assert np.array_equal(bits(got["rgb"][vis]), bits(want["rgb"][vis]))
+    assert np.array_equal(got["clamped"][vis], want["clamped"][vis])
+    assert np.array_equal(bits(got["color"]), bits(want["color"]))
+
+
+def test_mark_visible_and_empty(gpu, oracle):
+    from fisher_rast import ops
+    W = H = 64
+    sc = random_scene(5000, 12, zmin=-2.0, zmax=3.0)
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), _pose())
+    want = oracle.mark_visible(cam, sc["means3D"])
+    got = ops.mark_visible(to_dev(sc["means3D"], gpu), to_dev(cam.viewmatrix, gpu), to_dev(cam.projmatrix, gpu))
+    assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), want)
+    e = hip_forward(gpu, cam, np.zeros((0, 3), np.float32), np.zeros((0,), np.float32), colors_precomp=np.zeros((0, 3), np.float32),
+                    scales=np.zeros((0, 3), np.float32), rotations=np.zeros((0, 4), np.float32))
+    assert e["num_rendered"] == 0 and np.all(e["color"] == 0) and np.all(e["depth"] == 0) and e["radii"].shape == (0,)
+    # every splat culled: background image, default depth
+    behind = sc["means3D"].copy()
+    behind[:, 2] = -np.abs(behind[:, 2]) - 1
+    cam0 = oracle.setup_camera(W, H, intrinsics(W, H), np.eye(4))
+    o = hip_forward(gpu, cam0, behind, sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    assert o["num_rendered"] == 0 and np.all(o["radii"] == 0) and np.all(o["color"] == 0) and np.all(o["depth"] == 15.0)
+    assert np.all(o["final_T"] == 1.0) and np.all(o["ranges"] == 0)
+
+
+def test_argument_errors(gpu):
+    from fisher_rast import ops, FisherRastError
+    m = torch.zeros((4, 3), device=gpu)
+    one = torch.ones((4, 3), device=gpu)
+    eye = torch.eye(4, device=gpu)
+    e = torch.Tensor([])
+    with pytest.raises(RuntimeError):
+        ops.rasterize_forward(torch.zeros(3, device=gpu), torch.zeros((4, 2), device=gpu), one, one[:, :1], one, torch.ones((4, 4), device=gpu),
+                              1.0, e, eye, eye, 1.0, 1.0, 32, 32, e, 0, torch.zeros(3, device=gpu), False)
+    with pytest.raises(FisherRastError):   # neither colours nor SHs
+        ops.rasterize_forward(torch.zeros(3, device=gpu), m, e, one[:, :1], one, torch.ones((4, 4), device=gpu),
+                              1.0, e, eye, eye, 1.0, 1.0, 32, 32, e, 0, torch.zeros(3, device=gpu), False)
+    with pytest.raises(FisherRastError):   # CPU tensors: no CPU path
+        ops.mark_visible(torch.zeros((4, 3)), torch.eye(4), torch.eye(4))
