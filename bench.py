@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric): candidate views scored per second
+(+ Fisher scores per second) at 256x256 over 500k Gaussians.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic input: the fused scorer (fr_fisher_views) ranks
+`--views` (64) candidate poses per GPU against a resident 500k-Gaussian map and a resident H_inv = 1/(H_train+0.1):
+project/cull -> tile binning -> per-tile depth sort -> transmittance pass -> backward(power=2) -> sum(cur_H*H_inv).
+Inputs are in HBM before the timed region; each step ends with the asynchronous copy of the scores to the host.
+N = 1 : BASELINE.json configs[1] (500k Gaussians, 64 candidate 256x256 views, seed 2).
+N > 1 : configs[2]'s shape, weak scaling: every rank scores its own 64-view slice of a 64*N-view candidate set
+        (seed 3) and the per-view scores are exchanged with one RCCL all-gather per step.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "fisher-nerf-customized_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def cpu_baseline(P, W, H, seed, n_views, columns):
+    """The oracle (CPU restatement of the reference path, scalar, 1 thread) on a bounded sample of the same workload:
+    n_views candidate views of the same 500k-Gaussian scene, same H_inv construction (1 keyframe instead of 16)."""
+    from oracle import ref
+    from fisher_rast import synthetic
+    act = {k: v.numpy() for k, v in synthetic.activate(synthetic.room_shell(P, seed)).items()}
+    args = (act["means3D"], act["rgb_colors"], act["rotations"], act["opacities"], act["scales"])
+    cam = ref.setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4))
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(n_views, seed)).numpy()
+    kf = synthetic.invert_rigid(synthetic.candidate_poses(1, seed + 100)).numpy()
+    H_train = ref.compute_h_train(cam, kf, *args, columns=columns)
+    t0 = time.perf_counter()
+    scores, _ = ref.pose_eval(cam, w2c, H_train, *args, columns=columns)
+    dt = time.perf_counter() - t0
+    return dict(value=n_views / dt, unit="candidate-views/s", cores=1, kind="port",
+                sample=f"{n_views} of the {P}-Gaussian {W}x{H} candidate views through oracle/fisher_oracle.c "
+                       f"(forward + fused backward power=2 + weighted sum), {dt:.1f} s on 1 host core",
+                seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=500_000)
+    ap.add_argument("--views", type=int, default=64, help="candidate views per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--columns", type=int, default=4)
+    ap.add_argument("--cpu-views", type=int, default=4, help="views of the CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from fisher_rast import synthetic, _lib, distributed as D
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+
+    P, V, W, H, C = a.gaussians, a.views, a.size, a.size, a.columns
+    seed = 2 if world == 1 else 3
+    act = synthetic.activate(synthetic.room_shell(P, seed))
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=dev)
+    scorer = FisherScorer(cam, *(act[k].to(dev) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")),
+                          columns=C, dL_dpix=1e-3)
+    w2c_all = synthetic.invert_rigid(synthetic.candidate_poses(V * world, seed)).to(dev)
+    lo, hi = D.shard_bounds(V * world, rank, world)
+    w2c = w2c_all[lo:hi].contiguous()
+    kf = synthetic.invert_rigid(synthetic.candidate_poses(16, seed + 100)).to(dev)
+
+    # H_train: keyframes sharded over ranks + one all-reduce(SUM)  (outside the timed region: it is an input)
+    H_train = torch.zeros((P, C), dtype=torch.float32, device=dev)
+    D.sharded_h_train(lambda w, Hacc: scorer.run(w, out_H=Hacc), kf, H_train)
+    H_inv = torch.reciprocal(H_train + 0.1)
+    first = scorer.run(w2c, H_inv=H_inv)      # sizes the tile-instance buffer (may re-run on overflow)
+    num_rendered = first["num_rendered"].cpu().numpy().astype(np.int64)
+    vis_count = first["vis_count"].cpu().numpy().astype(np.int64)
+
+    host_scores = torch.empty((V * world,), dtype=torch.float32).pin_memory()
+    gathered = torch.empty((V * world,), dtype=torch.float32, device=dev)
+
+    def step():
+        r = scorer.launch(w2c, H_inv=H_inv)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, r["scores"])
+            host_scores.copy_(gathered, non_blocking=True)
+        else:
+            host_scores.copy_(r["scores"], non_blocking=True)
+        return r
+
+    for _ in range(a.warmup):
+        step()
+    lib = _lib.load()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.fr_profile_enable(1)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    buf = (ctypes.c_float * max(a.steps, 1))()
+    n_ev = lib.fr_profile_fetch(buf, a.steps)
+    lib.fr_profile_enable(0)
+    assert int(last["status"].cpu()[1]) == 0, "tile-instance buffer overflowed inside the timed region"
+    kern_ms = float(np.mean([buf[i] for i in range(n_ev)])) if n_ev > 0 else float("nan")
+
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+
+    if rank == 0:
+        views_per_s = V * world * a.steps / dt
+        R = float(num_rendered.sum())          # tile instances of this rank's V views
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        # algorithmic bytes of ONE k_fisher_tile launch (DESIGN.md "k_fisher_tile"): per tile instance the transmittance
+        # pass reads key 8 + xy 8 + conic_opacity 16 and the backward pass reads those again + rgb 12 + mean 12 +
+        # cov3D 24 + H_inv 4*C; plus one partial score per tile.
+        kern_bytes = R * (32 + 32 + 12 + 12 + 24 + 4 * C) + 4.0 * V * T
+        ach = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
+        # whole-path algorithmic bytes per view, SURVEY.md 8(d)
+        B_view = (12 * P + 44 * vis_count.mean() + 24 * num_rendered.mean() + 40 * num_rendered.mean() +
+                  40 * num_rendered.mean() + 24 * W * H + 8 * W * H + 4 * C * P)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile.json")
+        if os.path.exists(pmc_file):
+            try:
+                pm = json.load(open(pmc_file))
+                if pm.get("gaussians") == P and pm.get("views") == V and pm.get("size") == W and pm.get("columns") == C:
+                    traffic = pm.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "candidate-views/sec", "value": views_per_s, "unit": "candidate-views/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{P} Gaussians (room_shell seed {seed}), {V} candidate {W}x{H} views per GPU per step, "
+                                   f"Fisher columns {C}, H_inv from 16 keyframes; BASELINE.json configs[{1 if world == 1 else 2}]",
+                       "gaussians": P, "views_per_gpu": V, "image": [H, W], "columns": C,
+                       "tile_instances_per_view": float(num_rendered.mean()), "visible_per_view": float(vis_count.mean()),
+                       "parallelism": f"views sharded over {world} GPU(s), scores all-gathered" if world > 1 else "1 GPU"},
+            "fisher_scores_per_s": views_per_s * P * C,
+            "roofline": {"bound": "hbm", "kernel": "k_fisher_tile", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
+                         "kernel_share_of_step": (kern_ms / (1e3 * dt / a.steps)) if kern_ms == kern_ms else None},
+            "path": {"bytes_per_view": float(B_view), "achieved_GBps": float(B_view * views_per_s / world / 1e9),
+                     "frac_of_hbm_peak": float(B_view * views_per_s / world / 1e9 / HBM_PEAK_GBS)},
+        }
+        if world == 1 and a.cpu_views > 0:
+            out["cpu_baseline"] = cpu_baseline(P, W, H, seed, a.cpu_views, C)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

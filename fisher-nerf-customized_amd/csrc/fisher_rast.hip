@@ -34,7 +34,12 @@
 #define FR_BATCH 256                 // splats staged per round in the forward pass
 #define FR_BWD_BATCH 128             // splats staged per round in the backward passes
 
+#include <vector>
+#include <utility>
 static thread_local char g_err[512] = "";
+// measurement only: HIP events recorded around the dominant kernel on the stream it is launched on
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static int fr_fail(int code, const char* msg)
 {
 	snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -1230,8 +1235,19 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.H_inv = fc->H_inv; f.hinv_stride = fc->H_inv_view_stride;
 	f.out_H = fc->out_H; f.outH_stride = fc->out_H_view_stride;
 	f.tile_scores = (float*)(ws + L.tile_scores);
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (g_prof_on)
+	{
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, s);
+	}
 	if (fc->columns == 4) fr_launch_fisher<4>(p, f, s);
 	else fr_launch_fisher<11>(p, f, s);
+	if (g_prof_on)
+	{
+		(void)hipEventRecord(ev1, s);
+		g_prof_events.push_back(std::make_pair(ev0, ev1));
+	}
 	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
 	if (fc->out_scores)
 	{
@@ -1497,4 +1513,27 @@ extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* wo
 	hipLaunchKernelGGL(k_knn_boxes, dim3(nb), dim3(FR_THREADS), 0, s, P, sorted, boxes);
 	hipLaunchKernelGGL(k_knn_search, dim3(nblk), dim3(FR_THREADS), 0, s, P, sorted, keys, boxes, nb, out);
 	return fr_check_launch("k_knn_search");
+}
+
+// ---- measurement hooks (bench.py): per-launch duration of k_fisher_tile from HIP events on its own stream --------
+extern "C" int fr_profile_enable(int on)
+{
+	for (auto& e : g_prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+	g_prof_events.clear();
+	g_prof_on = on != 0;
+	return FR_OK;
+}
+
+extern "C" int fr_profile_fetch(float* ms, int max_n)
+{
+	int n = 0;
+	for (auto& e : g_prof_events)
+	{
+		if (n >= max_n) break;
+		if (hipEventSynchronize(e.second) != hipSuccess) return -1;
+		float t = 0.f;
+		if (hipEventElapsedTime(&t, e.first, e.second) != hipSuccess) return -1;
+		ms[n++] = t;
+	}
+	return n;
 }

@@ -64,7 +64,7 @@ class FisherCfg(ctypes.Structure):
 EXPORTS = (
     "fr_version", "fr_last_error", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
     "fr_forward", "fr_backward", "fr_fisher_workspace_bytes", "fr_fisher_views",
-    "fr_knn_workspace_bytes", "fr_knn_dist2",
+    "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
 )
 
 _lib = None
@@ -117,6 +117,10 @@ def load():
     lib.fr_knn_workspace_bytes.argtypes = [ctypes.c_int32]
     lib.fr_knn_dist2.restype = ctypes.c_int
     lib.fr_knn_dist2.argtypes = [ctypes.c_int32, _f32p, _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.fr_profile_enable.restype = ctypes.c_int
+    lib.fr_profile_enable.argtypes = [ctypes.c_int]
+    lib.fr_profile_fetch.restype = ctypes.c_int
+    lib.fr_profile_fetch.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     _lib = lib
     return lib
 

@@ -155,6 +155,15 @@ size_t fr_knn_workspace_bytes(int32_t P);
 int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
                  fr_stream_t stream);
 
+/* ---- measurement hooks (not part of the reference surface) ------------------------------------------ */
+
+/* When enabled, every fr_fisher_views call records a pair of HIP events around its dominant kernel
+ * (k_fisher_tile) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
+int fr_profile_enable(int on);
+/* Waits for the recorded events and writes up to max_n per-launch durations in milliseconds; returns the count
+ * (or -1 on a HIP error).  This is the only entry point that blocks. */
+int fr_profile_fetch(float* ms, int max_n);
+
 #ifdef __cplusplus
 }
 #endif

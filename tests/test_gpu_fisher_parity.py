@@ -131,16 +131,20 @@ def test_render_at_pose_matches_oracle(config1, gpu, oracle):
     slam = mgs.GaussianSLAM(params=c["params"], intrinsics=c["K"], width=c["W"], height=c["H"], device=gpu)
     out = slam.render_at_pose(c["c2w"][2].to(gpu))
     assert out["render"].shape == (3, c["H"], c["W"]) and out["depth"].shape == (1, c["H"], c["W"])
-    # same transformed points fed to the oracle
+    # feed the oracle exactly what the surface fed the rasteriser: device-side transform and activations
+    from models.SLAM.utils.slam_helpers import transformed_params2rendervar, transformed_params2depthplussilhouette
     rel_w2c = torch.linalg.inv(c["c2w"][2].to(gpu))
-    pts = c["params"]["means3D"].to(gpu)
-    tp = (rel_w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3].cpu().numpy()
-    a = c["args"]
-    fw = oracle.rasterize_forward(c["ocam"], tp, a[3], colors_precomp=a[1], scales=a[4], rotations=a[2])
+    pts = slam.params["means3D"]
+    tp = (rel_w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3]
+    rv = transformed_params2rendervar(slam.params, tp)
+    n = {k: v.detach().cpu().numpy() for k, v in rv.items()}
+    fw = oracle.rasterize_forward(c["ocam"], n["means3D"], n["opacities"], colors_precomp=n["colors_precomp"],
+                                  scales=n["scales"], rotations=n["rotations"])
     assert np.array_equal(out["render"].detach().cpu().numpy().view(np.uint32), fw["color"].view(np.uint32))
-    depth_col = np.stack([tp[:, 2], np.ones_like(tp[:, 2]), tp[:, 2] ** 2], 1).astype(np.float32)
-    fd = oracle.rasterize_forward(c["ocam"], tp, a[3], colors_precomp=depth_col, scales=a[4], rotations=a[2])
-    assert rel_err(out["depth"].detach().cpu().numpy()[0], fd["color"][0]) < 1e-6
+    dv = transformed_params2depthplussilhouette(slam.params, slam.first_frame_w2c, tp)
+    fd = oracle.rasterize_forward(c["ocam"], n["means3D"], n["opacities"], colors_precomp=dv["colors_precomp"].cpu().numpy(),
+                                  scales=n["scales"], rotations=n["rotations"])
+    assert np.array_equal(out["depth"].detach().cpu().numpy()[0].view(np.uint32), fd["color"][0].view(np.uint32))
 
 
 def test_overflow_regrow_and_chunking(config1, gpu):
