@@ -28,9 +28,10 @@
 #include "../../include/fisher_rast.h"
 
 #define FR_THREADS 256
-#define FR_G_PER_THREAD 4            // Gaussians per thread in the per-Gaussian kernels
+#define FR_G_MAX 32                  // upper bound of Gaussians per thread in the per-Gaussian kernels (FrParams::G)
 #define FR_MAX_LDS_TILES 4096        // tile histogram kept in LDS up to 1024x1024 images
-#define FR_SORT_LDS_KEYS 4096        // per-tile segments up to this size are sorted in LDS (32 KiB)
+#define FR_SORT_SMALL_KEYS 2048      // per-tile segments up to this size: 16 KiB of LDS, many workgroups per CU
+#define FR_SORT_BIG_KEYS 16384       // up to this size: 128 KiB of LDS, one workgroup per CU; beyond: global memory
 #define FR_BATCH 256                 // splats staged per round in the forward pass
 #define FR_BWD_BATCH 128             // splats staged per round in the backward passes
 
@@ -57,10 +58,14 @@ static int fr_check_launch(const char* what)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Everything preprocess derives for one (view, Gaussian): one 32-byte record = one sector per gather.
+struct FrSplat { float x, y, cx, cy, cz, o, depth, pad; };
+
 struct FrParams {
 	int P, V, W, H;
 	uint32_t gx, gy;
 	int T;                       // tiles per view
+	int G;                       // Gaussians per thread in k_preprocess / k_scatter_keys
 	float tanfovx, tanfovy, focal_x, focal_y, mod;
 	int D, M;
 	const float* bg; const float* view; const float* proj; const float* campos;
@@ -70,13 +75,12 @@ struct FrParams {
 	const float* cov3D;          // [P][6] (precomputed input or output of k_cov3d)
 	float* cov3D_out;
 	int* radii;                  // [V][P]
-	float* depths;               // [V][P]
-	fr_f2* means2D;              // [V][P]
-	fr_f4* conic_op;             // [V][P]
+	FrSplat* splat;              // [V][P] 32-byte records, written only where radii > 0
 	float* rgb;                  // [V][P][3]  (SH path only)
 	uint8_t* clamped;            // [V][P][3]
 	uint32_t* tile_cnt; uint32_t* tile_off; uint32_t* tile_fill; // [V][T]
 	uint64_t* keys; long long key_capacity;
+	uint32_t* big_list;          // [0] = number of tiles with more than FR_SORT_SMALL_KEYS splats, [16..] their (view*T + tile)
 	int* status;                 // [4]
 	int* vis_count;              // [V] or null
 	int* num_rendered;           // [V] or null
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 	uint32_t* cnt = p.tile_cnt + (size_t)v * p.T;
 	const size_t vP = (size_t)v * p.P;
 	int nvis = 0;
-	for (int g = 0; g < FR_G_PER_THREAD; g++)
+	for (int g = 0; g < p.G; g++)
 	{
-		const int i = (blockIdx.x * FR_G_PER_THREAD + g) * FR_THREADS + tid;
+		const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
 		if (i >= p.P) break;
 		fr_f3 pw = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
 		fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
@@ -173,11 +177,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 		if (s.radius > 0)
 		{
 			nvis++;
-			p.depths[vP + i] = s.depth;
-			fr_f2 xy = { s.px, s.py };
-			p.means2D[vP + i] = xy;
-			fr_f4 co = { s.conx, s.cony, s.conz, p.opac[i] };
-			p.conic_op[vP + i] = co;
+			float4* dst = (float4*)(p.splat + vP + i);
+			dst[0] = make_float4(s.px, s.py, s.conx, s.cony);
+			dst[1] = make_float4(s.conz, p.opac[i], s.depth, 0.f);
 			if (p.colors == nullptr)
 			{
 				fr_f3 cp = { p.campos[0], p.campos[1], p.campos[2] };
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
                                                      uint32_t* __restrict__ fill, int N, int T, int V,
                                                      long long capacity, int* __restrict__ status,
-                                                     int* __restrict__ num_rendered)
+                                                     int* __restrict__ num_rendered, uint32_t* __restrict__ big_list)
 {
 	__shared__ uint32_t wsum[16];
 	__shared__ uint32_t chunk_total;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 		const int i = base + tid;
 		const uint32_t c = i < N ? cnt[i] : 0u;
 		maxc = c > maxc ? c : maxc;
+		if (c > (uint32_t)FR_SORT_SMALL_KEYS) big_list[16 + atomicAdd(&big_list[0], 1u)] = (uint32_t)i;
 		uint32_t x = c;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1)
@@ -289,30 +292,83 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 {
+	// Block-aggregated slot claims: count this block's instances per tile in LDS, claim one contiguous range per
+	// non-empty tile with a single global atomic, then hand out slots inside the ranges with LDS atomics.  (The order
+	// of a tile's segment is irrelevant: k_sort_tiles sorts it and the keys are unique.)
+	__shared__ uint32_t s_cnt[FR_MAX_LDS_TILES];
+	__shared__ uint32_t s_base[FR_MAX_LDS_TILES];
 	if (p.status[1]) return;
 	const int tid = threadIdx.x;
 	const int v = blockIdx.y;
 	const size_t vP = (size_t)v * p.P;
 	const uint32_t* off = p.tile_off + (size_t)v * p.T;
 	uint32_t* fill = p.tile_fill + (size_t)v * p.T;
-	for (int g = 0; g < FR_G_PER_THREAD; g++)
+	const bool lds = p.T <= FR_MAX_LDS_TILES;
+	if (lds)
 	{
-		const int i = (blockIdx.x * FR_G_PER_THREAD + g) * FR_THREADS + tid;
+		for (int t = tid; t < p.T; t += FR_THREADS) s_cnt[t] = 0;
+		__syncthreads();
+		for (int g = 0; g < p.G; g++)
+		{
+			const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
+			if (i >= p.P) break;
+			const int rad = p.radii[vP + i];
+			if (rad > 0)
+			{
+				const float2 xy = *(const float2*)(p.splat + vP + i);
+				const fr_rect rc = fr_get_rect(xy.x, xy.y, rad, p.gx, p.gy);
+				for (uint32_t y = rc.y0; y < rc.y1; y++)
+					for (uint32_t x = rc.x0; x < rc.x1; x++)
+						atomicAdd(&s_cnt[y * p.gx + x], 1u);
+			}
+		}
+		__syncthreads();
+		for (int t = tid; t < p.T; t += FR_THREADS)
+		{
+			const uint32_t c = s_cnt[t];
+			if (c) s_base[t] = off[t] + atomicAdd(&fill[t], c);
+			s_cnt[t] = 0;
+		}
+		__syncthreads();
+	}
+	for (int g = 0; g < p.G; g++)
+	{
+		const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
 		if (i >= p.P) break;
 		const int rad = p.radii[vP + i];
 		if (rad > 0)
 		{
-			const fr_f2 xy = p.means2D[vP + i];
-			const uint64_t hi = ((uint64_t)fr_as_u32(p.depths[vP + i])) << 32;
+			const FrSplat* sp = p.splat + vP + i;
+			const float2 xy = *(const float2*)sp;
+			const uint64_t hi = ((uint64_t)fr_as_u32(sp->depth)) << 32;
 			const fr_rect rc = fr_get_rect(xy.x, xy.y, rad, p.gx, p.gy);
 			for (uint32_t y = rc.y0; y < rc.y1; y++)
 				for (uint32_t x = rc.x0; x < rc.x1; x++)
 				{
 					const uint32_t t = y * p.gx + x;
-					const uint32_t slot = off[t] + atomicAdd(&fill[t], 1u);
+					const uint32_t slot = lds ? (s_base[t] + atomicAdd(&s_cnt[t], 1u)) : (off[t] + atomicAdd(&fill[t], 1u));
 					p.keys[slot] = hi | (uint32_t)i;
 				}
 		}
+	}
+}
+
+// XCD-aware (tile, view) of a 1-D grid of T*V workgroups: workgroups b and b+8 share an XCD (and its L2), so every
+// XCD is given whole views -- the tiles of one view then gather that view's per-splat records through one L2.
+// Placement is a speed matter only; the map is a bijection whenever V % 8 == 0 and the plain one otherwise.
+__device__ __forceinline__ void fr_tile_of_block(const FrParams& p, uint32_t& tile, int& v)
+{
+	const uint32_t L = blockIdx.x;
+	if ((p.V & 7) == 0)
+	{
+		const uint32_t xcd = L & 7u, q = L >> 3;
+		v = (int)((q / (uint32_t)p.T) * 8u + xcd);
+		tile = q % (uint32_t)p.T;
+	}
+	else
+	{
+		v = (int)(L / (uint32_t)p.T);
+		tile = L % (uint32_t)p.T;
 	}
 }
 
@@ -320,14 +376,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 // Ascending-only bitonic network ("flip" form): works for any n without padding, because a comparator whose
 // upper element lies beyond n would compare against +inf and never swap.
 template <typename KeyPtr>
-__device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid)
+__device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid, const uint32_t FR_NT = FR_THREADS)
 {
 	uint32_t n_pad = 1;
 	while (n_pad < n) n_pad <<= 1;
 	for (uint32_t k = 2; k <= n_pad; k <<= 1)
 	{
 		// flip stage: i <-> i ^ (k-1)
-		for (uint32_t t = tid; t < (n_pad >> 1); t += FR_THREADS)
+		for (uint32_t t = tid; t < (n_pad >> 1); t += FR_NT)
 		{
 			const uint32_t half = k >> 1;
 			const uint32_t i = ((t / half) * k) + (t % half);
@@ -341,7 +397,7 @@ __device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid)
 		__syncthreads();
 		for (uint32_t j = k >> 2; j > 0; j >>= 1)
 		{
-			for (uint32_t t = tid; t < (n_pad >> 1); t += FR_THREADS)
+			for (uint32_t t = tid; t < (n_pad >> 1); t += FR_NT)
 			{
 				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
 				const uint32_t l = i + j;
@@ -356,27 +412,46 @@ __device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid)
 	}
 }
 
+// Segments of up to FR_SORT_SMALL_KEYS keys: one workgroup per (tile, view), 16 KiB of LDS.
 __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 {
 	if (p.status[1]) return;
-	__shared__ uint64_t skeys[FR_SORT_LDS_KEYS];
+	__shared__ uint64_t skeys[FR_SORT_SMALL_KEYS];
 	const int tid = threadIdx.x;
-	const size_t vt = (size_t)blockIdx.y * p.T + blockIdx.x;
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const size_t vt = (size_t)v * p.T + tile;
 	const uint32_t n = p.tile_cnt[vt];
-	if (n < 2) return;
+	if (n < 2 || n > (uint32_t)FR_SORT_SMALL_KEYS) return;
 	uint64_t* gk = p.keys + p.tile_off[vt];
-	if (n <= FR_SORT_LDS_KEYS)
+	for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
+	__syncthreads();
+	fr_bitonic(skeys, n, tid, FR_THREADS);
+	for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+}
+
+// The few larger segments (listed by k_scan_tiles): 1024 threads, 128 KiB of LDS, grid-stride over the list; segments
+// beyond FR_SORT_BIG_KEYS run the same network on global memory (__syncthreads orders the workgroup's own accesses).
+__global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
+{
+	if (p.status[1]) return;
+	__shared__ uint64_t skeys[FR_SORT_BIG_KEYS];
+	const int tid = threadIdx.x;
+	const uint32_t count = p.big_list[0];
+	for (uint32_t b = blockIdx.x; b < count; b += gridDim.x)
 	{
-		for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
+		const size_t vt = p.big_list[16 + b];
+		const uint32_t n = p.tile_cnt[vt];
+		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
-		fr_bitonic(skeys, n, tid);
-		for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
-	}
-	else
-	{
-		// rare: a tile with more splats than the LDS segment; same network straight on global memory
-		// (__syncthreads orders the workgroup's own global accesses)
-		fr_bitonic(gk, n, tid);
+		if (n <= (uint32_t)FR_SORT_BIG_KEYS)
+		{
+			for (uint32_t i = tid; i < n; i += 1024) skeys[i] = gk[i];
+			__syncthreads();
+			fr_bitonic(skeys, n, tid, 1024);
+			for (uint32_t i = tid; i < n; i += 1024) gk[i] = skeys[i];
+		}
+		else fr_bitonic(gk, n, tid, 1024);
 	}
 }
 
@@ -434,8 +509,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
 		{
 			const uint64_t key = gk[k];
 			const uint32_t id = (uint32_t)key;
-			s_xy[tid] = p.means2D[vP + id];
-			const fr_f4 co = p.conic_op[vP + id];
+			const float4* sp = (const float4*)(p.splat + vP + id);
+			const float4 q0 = sp[0], q1 = sp[1];
+			fr_f2 xy = { q0.x, q0.y };
+			s_xy[tid] = xy;
+			const fr_f4 co = { q0.z, q0.w, q1.x, q1.y };
 			s_co[tid] = co;
 			s_thr[tid] = fr_power_threshold(co.w);
 			s_depth[tid] = fr_as_f32((uint32_t)(key >> 32));
@@ -529,6 +607,7 @@ struct FrFisherArgs {
 	const float* H_inv; long long hinv_stride;
 	float* out_H; long long outH_stride;
 	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
+	const uint8_t* only_flagged; // [V][T] or null: when set, k_fisher_tile handles only the flagged tiles
 };
 
 template <int C, bool HAS_HINV, bool HAS_OUTH>
@@ -547,13 +626,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int v = blockIdx.y;
-	const uint32_t tile = blockIdx.x;
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
 	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
 	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
 	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
 	const float pfx = (float)pxx, pfy = (float)pxy;
 	const size_t vt = (size_t)v * p.T + tile;
+	if (f.only_flagged && !f.only_flagged[vt]) return;
 	const size_t vP = (size_t)v * p.P;
 	const uint32_t n = p.tile_cnt[vt];
 	const uint64_t* gk = p.keys + p.tile_off[vt];
@@ -569,8 +649,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 		if (k < n)
 		{
 			const uint32_t id = (uint32_t)gk[k];
-			s_xy[tid] = p.means2D[vP + id];
-			const fr_f4 co = p.conic_op[vP + id];
+			const float4* sp = (const float4*)(p.splat + vP + id);
+			const float4 q0 = sp[0], q1 = sp[1];
+			fr_f2 xy_ = { q0.x, q0.y };
+			s_xy[tid] = xy_;
+			const fr_f4 co = { q0.z, q0.w, q1.x, q1.y };
 			s_co[tid] = co;
 			s_thr[tid] = fr_power_threshold(co.w);
 		}
@@ -629,8 +712,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 		{
 			const uint32_t id = (uint32_t)gk[remaining - 1 - tid];
 			s_id[tid] = id;
-			s_xy[tid] = p.means2D[vP + id];
-			const fr_f4 co = p.conic_op[vP + id];
+			const float4* sp = (const float4*)(p.splat + vP + id);
+			const float4 q0 = sp[0], q1 = sp[1];
+			fr_f2 xy_ = { q0.x, q0.y };
+			s_xy[tid] = xy_;
+			const fr_f4 co = { q0.z, q0.w, q1.x, q1.y };
 			s_co[tid] = co;
 			s_thr[tid] = fr_power_threshold(co.w);
 			s_rgb[0][tid] = p.colors[3 * (size_t)id]; s_rgb[1][tid] = p.colors[3 * (size_t)id + 1]; s_rgb[2][tid] = p.colors[3 * (size_t)id + 2];
@@ -733,6 +819,364 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Scoring path, second generation.
+//
+// k_build_records   one pass over the sorted tile instances: gathers everything a (pixel, splat) pair needs and the
+//                   per-instance Jacobian rows into two streams laid out in list order:
+//                     recA[s] (32 B) = { xy, conic, opacity, power threshold, id }            -- read by both passes
+//                     recB[s]        = { rgb[3], A[3][5], (Cm[7][3]), H_inv[C], pad }         -- read by pass 2
+//                   so the tile kernel streams its splats instead of gathering them, and the register-hungry
+//                   Jacobian chain lives in a kernel of its own.
+// k_fisher_tile_v2  pass 1 (transmittance) additionally records, per wave, WHICH splats touched its 16x4 strip.
+//                   pass 2 is wave-private: a wave walks only its own list, 64 entries at a time held one per lane in
+//                   registers; every lane first builds a 64-bit mask of the entries that contribute to ITS pixel
+//                   (v_readlane broadcast + the same pair test), then walks its own set bits back to front, fetching
+//                   the record it needs from the owning lane with ds_bpermute.  All 64 lanes do useful work on every
+//                   step instead of the whole wave executing one splat for the few pixels it covers.
+// Tiles whose lists do not fit the LDS index (u16 positions, FR_WCAP per wave) are flagged and redone by k_fisher_tile.
+// ---------------------------------------------------------------------------------------------------------
+#define FR_WCAP 3840                 // per-wave list capacity (u16 positions): 30 KiB; LDS stays under the 40 KiB that 4 workgroups/CU allow
+
+struct FrRecA { float x, y, cx, cy, cz, o, thr; uint32_t box; };
+
+template <int C> struct FrRecBSize { static constexpr int value = (C == 11) ? 52 : 24; };
+
+// View-independent inputs of one Gaussian packed into one record: { mean[3], cov3D[6], rgb[3], (scale[3], rot[4]),
+// H_inv[C] } = 16 floats (64 B, one cache line) at C = 4, 32 floats at C = 11.  k_build_records then needs two gathers
+// per tile instance (this record and the 32-byte FrSplat) instead of six.  With per-view H_inv the weights are
+// gathered separately.
+template <int C> struct FrPackSize { static constexpr int value = (C == 11) ? 32 : 16; };
+
+template <int C>
+__global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed)
+{
+	constexpr int PS = FrPackSize<C>::value;
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= p.P) return;
+	float b[PS];
+#pragma unroll
+	for (int k = 0; k < PS; k++) b[k] = 0.f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) b[k] = p.means3D[3 * (size_t)i + k];
+#pragma unroll
+	for (int k = 0; k < 6; k++) b[3 + k] = p.cov3D[6 * (size_t)i + k];
+#pragma unroll
+	for (int k = 0; k < 3; k++) b[9 + k] = p.colors[3 * (size_t)i + k];
+	int o = 12;
+	if constexpr (C == 11)
+	{
+#pragma unroll
+		for (int k = 0; k < 3; k++) b[12 + k] = p.scales[3 * (size_t)i + k];
+#pragma unroll
+		for (int k = 0; k < 4; k++) b[15 + k] = p.rots[4 * (size_t)i + k];
+		o = 19;
+	}
+	if (H_inv)
+	{
+#pragma unroll
+		for (int c = 0; c < C; c++) b[o + c] = H_inv[(size_t)i * C + c];
+	}
+	float4* dst = (float4*)(packed + (size_t)i * PS);
+#pragma unroll
+	for (int k = 0; k < PS / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
+}
+
+// Conservative tile-local pixel box of the pixels for which `power >= thr` can hold (i.e. alpha can reach 1/255):
+// the ellipse 1/2 d^T Q d <= -thr has half extents sqrt(-2 thr * Sigma_xx), sqrt(-2 thr * Sigma_yy), Sigma = Q^-1.
+// Packed as y0 | y1 << 8 | x0 << 16 | x1 << 24 (tile-local, inclusive); y0 > y1 means "no pixel of this tile".
+__device__ __forceinline__ uint32_t fr_pixel_box(float mx, float my, float cx, float cy, float cz, float thr, uint32_t px0, uint32_t py0)
+{
+	const uint32_t full = 0u | (15u << 8) | (0u << 16) | (15u << 24);
+	const uint32_t none = 1u | (0u << 8);
+	if (!(thr <= 0.f)) return none;              // opacity <= 1/255 (or NaN): never reaches the alpha threshold
+	const float det = cx * cz - cy * cy;
+	if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return full;
+	const float tau2 = -2.0f * thr;
+	const float hx = sqrtf(tau2 * cz / det) * 1.01f + 0.01f;
+	const float hy = sqrtf(tau2 * cx / det) * 1.01f + 0.01f;
+	if (!(hx == hx) || !(hy == hy)) return full;
+	const float fx0 = ceilf(mx - hx) - (float)px0, fx1 = floorf(mx + hx) - (float)px0;
+	const float fy0 = ceilf(my - hy) - (float)py0, fy1 = floorf(my + hy) - (float)py0;
+	if (fx1 < 0.f || fy1 < 0.f || fx0 > 15.f || fy0 > 15.f) return none;
+	const uint32_t x0 = (uint32_t)fmaxf(fx0, 0.f), x1 = (uint32_t)fminf(fx1, 15.f);
+	const uint32_t y0 = (uint32_t)fmaxf(fy0, 0.f), y1 = (uint32_t)fminf(fy1, 15.f);
+	return y0 | (y1 << 8) | (x0 << 16) | (x1 << 24);
+}
+
+template <int C, bool PER_VIEW_HINV>
+__global__ __launch_bounds__(FR_THREADS) void k_build_records(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
+                                                              FrRecA* __restrict__ recA, float* __restrict__ recB)
+{
+	constexpr int RB = FrRecBSize<C>::value;
+	constexpr int PS = FrPackSize<C>::value;
+	if (p.status[1]) return;
+	const int tid = threadIdx.x;
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t n = p.tile_cnt[vt];
+	if (n == 0) return;
+	const size_t start = p.tile_off[vt];
+	const uint32_t px0 = (tile % p.gx) * FR_BLOCK_X, py0 = (tile / p.gx) * FR_BLOCK_Y;
+	float vm[16], pm[16], wm[12];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const bool has_w2c = p.w2c != nullptr;
+	if (has_w2c)
+	{
+#pragma unroll
+		for (int k = 0; k < 12; k++) wm[k] = p.w2c[16 * (size_t)v + k];
+	}
+	for (uint32_t i = tid; i < n; i += FR_THREADS)
+	{
+		const size_t s = start + i;
+		const uint32_t id = (uint32_t)p.keys[s];
+		const float4* sp = (const float4*)(p.splat + vP + id);
+		const float4 q0 = sp[0], q1 = sp[1];
+		const float thr = fr_power_threshold(q1.y);
+		const uint32_t box = fr_pixel_box(q0.x, q0.y, q0.z, q0.w, q1.x, thr, px0, py0);
+		float4* da = (float4*)(recA + s);
+		da[0] = q0;
+		da[1] = make_float4(q1.x, q1.y, thr, __uint_as_float(box));
+		float g[PS];
+		const float4* pk = (const float4*)(packed + (size_t)id * PS);
+#pragma unroll
+		for (int k = 0; k < PS / 4; k++) { const float4 t4 = pk[k]; g[4 * k] = t4.x; g[4 * k + 1] = t4.y; g[4 * k + 2] = t4.z; g[4 * k + 3] = t4.w; }
+		float b[RB];
+#pragma unroll
+		for (int k = 0; k < RB; k++) b[k] = 0.f;
+		b[0] = g[9]; b[1] = g[10]; b[2] = g[11];
+		fr_f3 pw = { g[0], g[1], g[2] };
+		fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+		float A[3][5];
+		float B[6][3];
+		fr_mean_jacobian(po, &g[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+#pragma unroll
+			for (int c = 0; c < 5; c++) b[3 + r * 5 + c] = A[r][c];
+		int o = 18, go = 12;
+		if constexpr (C == 11)
+		{
+			fr_f3 sc = { g[12], g[13], g[14] };
+			fr_f4 q = { g[15], g[16], g[17], g[18] };
+			float Cm[7][3];
+			fr_scale_rot_jacobian(sc, p.mod, q, B, Cm);
+#pragma unroll
+			for (int r = 0; r < 7; r++)
+#pragma unroll
+				for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cm[r][c];
+			o = 39; go = 19;
+		}
+		if constexpr (PER_VIEW_HINV)
+		{
+			const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
+#pragma unroll
+			for (int c = 0; c < C; c++) b[o + c] = hp[c];
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < C; c++) b[o + c] = g[go + c];
+		}
+		float4* dst = (float4*)(recB + s * RB);
+#pragma unroll
+		for (int k = 0; k < RB / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
+	}
+}
+
+__device__ __forceinline__ float fr_readlane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_float(__builtin_amdgcn_ds_bpermute(l << 2, __float_as_int(x))); }
+
+template <int C>
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const FrRecA* __restrict__ recA,
+                                                               const float* __restrict__ recB, uint8_t* __restrict__ fallback)
+{
+	constexpr int RB = FrRecBSize<C>::value;
+	constexpr int HO = (C == 11) ? 39 : 18;       // offset of H_inv inside a recB record
+	__shared__ float4 s_a0[FR_BATCH];
+	__shared__ float4 s_a1[FR_BATCH];
+	__shared__ uint16_t s_wl[4][FR_WCAP];
+	__shared__ float s_red[4];
+	__shared__ int s_ovf;
+
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const uint32_t n = p.tile_cnt[vt];
+	const size_t start = p.tile_off[vt];
+	if (n > 65535u)
+	{
+		if (tid == 0) fallback[vt] = 1;
+		return;
+	}
+	if (tid == 0) s_ovf = 0;
+
+	// ---- pass 1 ----
+	bool done = !inside;
+	float T = 1.0f;
+	int last = 0;
+	int wcnt = 0;                                  // wave-uniform
+	for (uint32_t base = 0; base < n; base += FR_BATCH)
+	{
+		if (__syncthreads_count(done) == FR_THREADS) break;
+		const uint32_t k = base + tid;
+		if (k < n)
+		{
+			const float4* src = (const float4*)(recA + start + k);
+			s_a0[tid] = src[0];
+			s_a1[tid] = src[1];
+		}
+		__syncthreads();
+		const int m = (int)min((uint32_t)FR_BATCH, n - base);
+		float4 a0n = s_a0[0], a1n = s_a1[0];
+		for (int j = 0; j < m; j++)
+		{
+			const float4 a0 = a0n, a1 = a1n;
+			if (j + 1 < m) { a0n = s_a0[j + 1]; a1n = s_a1[j + 1]; }   // next splat's record in flight during this one
+			// rows of this wave's 16x4 strip against the splat's conservative pixel box (wave-uniform skip)
+			const uint32_t box = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(a1.w));
+			if ((box & 0xffu) > (uint32_t)(4 * wave + 3) || ((box >> 8) & 0xffu) < (uint32_t)(4 * wave)) continue;
+			// forward.cu:338-357, predicated: same comparisons (written negated so that NaN behaves as in the reference)
+			const float dx = a0.x - pfx, dy = a0.y - pfy;
+			const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+			const bool pass = !done && !(power > 0.0f) && !(power < a1.z);
+			if (__any(pass))
+			{
+				const float G = fr_expf_inrange(power);
+				const float alpha = fminf(0.99f, a1.y * G);
+				const bool ok = pass && !(alpha < 1.0f / 255.0f);
+				const float test_T = T * (1 - alpha);
+				const bool kill = ok && (test_T < 0.0001f);
+				const bool contrib = ok && !kill;
+				done = done || kill;
+				T = contrib ? test_T : T;
+				last = contrib ? ((int)base + j + 1) : last;
+				if (__any(contrib))
+				{
+					// every lane stores the same value to the same address: no exec-mask juggling for a one-lane write
+					if (wcnt < FR_WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
+					wcnt++;
+				}
+			}
+		}
+	}
+	if (lane == 0 && wcnt > FR_WCAP) s_ovf = 1;
+	__syncthreads();
+	if (s_ovf)
+	{
+		if (tid == 0) fallback[vt] = 1;
+		return;
+	}
+	if (tid == 0) fallback[vt] = 0;
+
+	// ---- pass 2: wave-private, back to front ----
+	FrPixState st;
+	st.T_final = inside ? T : 0.f;
+	st.T = st.T_final;
+	st.accum0 = st.accum1 = st.accum2 = 0.f;
+	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
+	st.last_alpha = 0.f;
+	const float g = f.dL;
+	const float bg_dot = p.bg[0] * g + p.bg[1] * g + p.bg[2] * g;
+	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+	float score = 0.f;
+	const uint16_t* wl = s_wl[wave];
+
+	for (int hi = wcnt; hi > 0; hi -= 64)
+	{
+		const int m = min(64, hi);
+		// lane l owns list entry hi-1-l (descending position => bit order == back-to-front order)
+		int kk = 0x7fffffff;
+		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY;
+		float b[RB];
+#pragma unroll
+		for (int q = 0; q < RB; q++) b[q] = 0.f;
+		if (lane < m)
+		{
+			kk = (int)wl[hi - 1 - lane];
+			const float4* pa = (const float4*)(recA + start + kk);
+			const float4 a0 = pa[0], a1 = pa[1];
+			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = a1.z;
+			const float4* pb = (const float4*)(recB + (start + kk) * RB);
+#pragma unroll
+			for (int q = 0; q < RB / 4; q++)
+			{
+				const float4 t4 = pb[q];
+				b[4 * q] = t4.x; b[4 * q + 1] = t4.y; b[4 * q + 2] = t4.z; b[4 * q + 3] = t4.w;
+			}
+		}
+		// mask of the chunk entries that MAY contribute to this lane's pixel (the conservative power threshold only;
+		// the exact alpha test is repeated in the walk, on the one record the lane then holds)
+		unsigned long long mask = 0ull;
+		for (int j = 0; j < m; j++)
+		{
+			const int kj = __builtin_amdgcn_readlane(kk, j);
+			const float x = fr_readlane_f(ax, j), y = fr_readlane_f(ay, j);
+			const float cx = fr_readlane_f(acx, j), cy = fr_readlane_f(acy, j), cz = fr_readlane_f(acz, j);
+			const float thr = fr_readlane_f(athr, j);
+			const float dx = x - pfx, dy = y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			const bool act = inside && (kj < last) && !(power > 0.0f) && !(power < thr);
+			mask |= act ? (1ull << j) : 0ull;
+		}
+		// every lane walks its own set bits; the loop is wave-uniform so that all lanes take part in the bpermutes
+		while (__any(mask != 0ull))
+		{
+			bool has = mask != 0ull;
+			const int j = has ? (__ffsll((long long)mask) - 1) : 0;
+			mask &= mask - 1ull;
+			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
+			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
+			const float o = fr_bperm_f(ao, j);
+			float r[RB];
+#pragma unroll
+			for (int q = 0; q < RB; q++) r[q] = fr_bperm_f(b[q], j);
+			const float dx = x - pfx, dy = y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			const float G = fr_expf_inrange(power);
+			const float alpha = fminf(0.99f, o * G);
+			has = has && !(alpha < 1.0f / 255.0f);
+			if (has)
+			{
+				float m2x, m2y, qx, qy, qw, wcol, gop;
+				fr_pair_backward(st, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
+				                 m2x, m2y, qx, qy, qw, wcol, gop);
+#pragma unroll
+				for (int q = 0; q < 3; q++)
+				{
+					const float l = r[3 + q * 5 + 0] * m2x + r[3 + q * 5 + 1] * m2y + r[3 + q * 5 + 2] * qx
+					              + r[3 + q * 5 + 3] * qy + r[3 + q * 5 + 4] * qw;
+					score += (l * l) * r[HO + q];
+				}
+				score += (gop * gop) * r[HO + 3];
+				if constexpr (C == 11)
+				{
+#pragma unroll
+					for (int q = 0; q < 7; q++)
+					{
+						const float l = r[18 + q * 3 + 0] * qx + r[18 + q * 3 + 1] * qy + r[18 + q * 3 + 2] * qw;
+						score += (l * l) * r[HO + 4 + q];
+					}
+				}
+			}
+		}
+	}
+	const float ws = wave_sum(score);
+	if (lane == 0) s_red[wave] = ws;
+	__syncthreads();
+	if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
                                                               const int* __restrict__ status, float* __restrict__ out_scores)
 {
@@ -819,8 +1263,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 		{
 			const uint32_t id = (uint32_t)gk[remaining - 1 - tid];
 			s_id[tid] = id;
-			s_xy[tid] = p.means2D[id];
-			const fr_f4 co = p.conic_op[id];
+			const float4* sp = (const float4*)(p.splat + id);
+			const float4 q0 = sp[0], q1 = sp[1];
+			fr_f2 xy_ = { q0.x, q0.y };
+			s_xy[tid] = xy_;
+			const fr_f4 co = { q0.z, q0.w, q1.x, q1.y };
 			s_co[tid] = co;
 			s_thr[tid] = fr_power_threshold(co.w);
 			s_rgb[0][tid] = b.colors[3 * (size_t)id]; s_rgb[1][tid] = b.colors[3 * (size_t)id + 1]; s_rgb[2][tid] = b.colors[3 * (size_t)id + 2];
@@ -922,9 +1369,9 @@ static inline size_t fr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrLayout {
 	// geometry
-	size_t depths, means2D, conic_op, cov3D, rgb, clamped, geom_bytes;
+	size_t splat, cov3D, rgb, clamped, geom_bytes;
 	// image
-	size_t tile_cnt, tile_off, tile_fill, final_T, n_contrib, status, img_bytes;
+	size_t tile_cnt, tile_off, tile_fill, final_T, n_contrib, status, big_list, img_bytes;
 	// binning
 	size_t keys, bin_bytes;
 };
@@ -935,9 +1382,7 @@ static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t ma
 	const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
 	const size_t VP = (size_t)(V * P);
 	size_t o = 0;
-	L.depths = o; o = fr_align(o + VP * 4);
-	L.means2D = o; o = fr_align(o + VP * 8);
-	L.conic_op = o; o = fr_align(o + VP * 16);
+	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.rgb = o; o = fr_align(o + VP * 12);
 	L.clamped = o; o = fr_align(o + VP * 3);
@@ -949,6 +1394,7 @@ static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t ma
 	L.final_T = o; o = fr_align(o + (size_t)(V * W * H) * 4);
 	L.n_contrib = o; o = fr_align(o + (size_t)(V * W * H) * 4);
 	L.status = o; o = fr_align(o + 64);
+	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
 	L.img_bytes = o;
 	L.keys = 0;
 	L.bin_bytes = fr_align((size_t)(max_rendered > 0 ? max_rendered : 1) * 8);
@@ -966,13 +1412,13 @@ extern "C" int fr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_r
 	return FR_OK;
 }
 
-extern "C" int fr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t o[13])
+extern "C" int fr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t o[11])
 {
 	if (P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !o) return fr_fail(FR_EINVAL, "fr_workspace_layout: bad argument");
 	FrLayout L = fr_layout(P, W, H, 1, max_rendered);
-	o[0] = L.depths; o[1] = L.means2D; o[2] = L.conic_op; o[3] = L.cov3D; o[4] = L.rgb; o[5] = L.clamped;
-	o[6] = L.tile_cnt; o[7] = L.tile_off; o[8] = L.tile_fill; o[9] = L.final_T; o[10] = L.n_contrib; o[11] = L.status;
-	o[12] = L.keys;
+	o[0] = L.splat; o[1] = L.cov3D; o[2] = L.rgb; o[3] = L.clamped;
+	o[4] = L.tile_cnt; o[5] = L.tile_off; o[6] = L.tile_fill; o[7] = L.final_T; o[8] = L.n_contrib; o[9] = L.status;
+	o[10] = L.keys;
 	return FR_OK;
 }
 
@@ -1027,6 +1473,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 	const int P = p.P;
 	(void)hipMemsetAsync(p.tile_cnt, 0, (size_t)p.V * p.T * 4, s);
 	(void)hipMemsetAsync(p.status, 0, 16, s);
+	(void)hipMemsetAsync(p.big_list, 0, 64, s);
 	if (p.vis_count) (void)hipMemsetAsync(p.vis_count, 0, (size_t)p.V * 4, s);
 	if (g->cov3D_precomp) p.cov3D = g->cov3D_precomp;
 	else
@@ -1035,25 +1482,29 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 		if ((rc = fr_check_launch("k_cov3d"))) return rc;
 		p.cov3D = p.cov3D_out;
 	}
-	const int per_block = FR_THREADS * FR_G_PER_THREAD;
+	// enough Gaussians per workgroup for the LDS tile histograms to aggregate, enough workgroups to fill 256 CUs
+	long long gwant = ((long long)P * p.V) / ((long long)FR_THREADS * 2048);
+	p.G = (int)(gwant < 1 ? 1 : (gwant > FR_G_MAX ? FR_G_MAX : gwant));
+	const int per_block = FR_THREADS * p.G;
 	dim3 gridP((P + per_block - 1) / per_block, p.V);
 	hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_preprocess"))) return rc;
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
-	                   p.key_capacity, p.status, p.num_rendered);
+	                   p.key_capacity, p.status, p.num_rendered, p.big_list);
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
 	hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
-	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T, p.V), dim3(FR_THREADS), 0, s, p);
+	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
+	const int big_blocks = p.T * p.V < 512 ? p.T * p.V : 512;
+	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, s, p);
+	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
 	return FR_OK;
 }
 
 static void fr_carve_single(FrParams& p, const FrLayout& L, char* geom, char* bin, char* img)
 {
-	p.depths = (float*)(geom + L.depths);
-	p.means2D = (fr_f2*)(geom + L.means2D);
-	p.conic_op = (fr_f4*)(geom + L.conic_op);
+	p.splat = (FrSplat*)(geom + L.splat);
 	p.cov3D_out = (float*)(geom + L.cov3D);
 	p.rgb = (float*)(geom + L.rgb);
 	p.clamped = (uint8_t*)(geom + L.clamped);
@@ -1061,6 +1512,7 @@ static void fr_carve_single(FrParams& p, const FrLayout& L, char* geom, char* bi
 	p.tile_off = (uint32_t*)(img + L.tile_off);
 	p.tile_fill = (uint32_t*)(img + L.tile_fill);
 	p.status = (int*)(img + L.status);
+	p.big_list = (uint32_t*)(img + L.big_list);
 	p.keys = (uint64_t*)(bin + L.keys);
 }
 
@@ -1147,42 +1599,57 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 
 // ---- fused Fisher scorer ---------------------------------------------------------------------------------
 struct FrFisherLayout {
-	size_t radii, depths, means2D, conic_op, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, total;
+	size_t radii, splat, packed, big_list, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, recA, recB, total;
 };
-static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered)
+static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
 	FrFisherLayout L;
 	const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
 	const size_t VP = (size_t)(V * P);
 	size_t o = 0;
 	L.radii = o; o = fr_align(o + VP * 4);
-	L.depths = o; o = fr_align(o + VP * 4);
-	L.means2D = o; o = fr_align(o + VP * 8);
-	L.conic_op = o; o = fr_align(o + VP * 16);
+	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
+	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
+	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.tile_off = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.tile_fill = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.tile_scores = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.status = o; o = fr_align(o + 64);
-	L.keys = o; o = fr_align(o + (size_t)(max_rendered > 0 ? max_rendered : 1) * 8);
+	const size_t R = (size_t)(max_rendered > 0 ? max_rendered : 1);
+	L.keys = o; o = fr_align(o + R * 8);
+	L.fallback = o; o = fr_align(o + (size_t)(V * T));
+	L.recA = o; o = fr_align(o + R * sizeof(FrRecA));
+	L.recB = o; o = fr_align(o + R * 4 * (size_t)(columns == 11 ? FrRecBSize<11>::value : FrRecBSize<4>::value));
 	L.total = o;
 	return L;
 }
 
-extern "C" size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered)
+extern "C" size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns)
 {
-	if (P < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0) return 0;
-	return fr_fisher_layout(P, W, H, n_views, max_rendered).total;
+	if (P < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0 || (columns != 4 && columns != 11)) return 0;
+	return fr_fisher_layout(P, W, H, n_views, max_rendered, columns).total;
 }
 
 template <int C>
-static void fr_launch_fisher(const FrParams& p, const FrFisherArgs& f, hipStream_t s)
+static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, FrRecA* recA, float* recB, uint8_t* fallback, hipStream_t s)
 {
-	dim3 grid(p.T, p.V), block(FR_THREADS);
+	dim3 grid(p.T * p.V), block(FR_THREADS);
 	const bool hi = f.H_inv != nullptr, ho = f.out_H != nullptr;
+	f.only_flagged = nullptr;
 	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile<C, true, true>), grid, block, 0, s, p, f);
-	else if (hi) hipLaunchKernelGGL((k_fisher_tile<C, true, false>), grid, block, 0, s, p, f);
+	else if (hi)
+	{
+		// scores only: stream-ordered records + wave-private backward walk; flagged tiles are redone by the scan kernel
+		const bool per_view = f.hinv_stride != 0;
+		hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, per_view ? nullptr : f.H_inv, packed);
+		if (per_view) hipLaunchKernelGGL((k_build_records<C, true>), grid, block, 0, s, p, f, (const float*)packed, recA, recB);
+		else hipLaunchKernelGGL((k_build_records<C, false>), grid, block, 0, s, p, f, (const float*)packed, recA, recB);
+		hipLaunchKernelGGL((k_fisher_tile_v2<C>), grid, block, 0, s, p, f, (const FrRecA*)recA, (const float*)recB, fallback);
+		f.only_flagged = fallback;
+		hipLaunchKernelGGL((k_fisher_tile<C, true, false>), grid, block, 0, s, p, f);
+	}
 	else hipLaunchKernelGGL((k_fisher_tile<C, false, true>), grid, block, 0, s, p, f);
 }
 
@@ -1209,21 +1676,20 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		(void)hipMemsetAsync(status, 0, 16, s);
 		return FR_OK;
 	}
-	FrFisherLayout L = fr_fisher_layout(P, W, H, V, max_rendered);
+	FrFisherLayout L = fr_fisher_layout(P, W, H, V, max_rendered, fc->columns);
 	if (!workspace || workspace_bytes < L.total) return fr_fail(FR_ENOSPACE, "fr_fisher_views: workspace smaller than fr_fisher_workspace_bytes()");
 	char* ws = (char*)workspace;
 	FrParams p;
 	fr_fill_params(p, cfg, g, V);
 	p.w2c = fc->w2c;
 	p.radii = (int*)(ws + L.radii);
-	p.depths = (float*)(ws + L.depths);
-	p.means2D = (fr_f2*)(ws + L.means2D);
-	p.conic_op = (fr_f4*)(ws + L.conic_op);
+	p.splat = (FrSplat*)(ws + L.splat);
 	p.cov3D_out = (float*)(ws + L.cov3D);
 	p.tile_cnt = (uint32_t*)(ws + L.tile_cnt);
 	p.tile_off = (uint32_t*)(ws + L.tile_off);
 	p.tile_fill = (uint32_t*)(ws + L.tile_fill);
 	p.status = (int*)(ws + L.status);
+	p.big_list = (uint32_t*)(ws + L.big_list);
 	p.keys = (uint64_t*)(ws + L.keys);
 	p.key_capacity = max_rendered;
 	p.vis_count = fc->out_vis_count;
@@ -1235,14 +1701,15 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.H_inv = fc->H_inv; f.hinv_stride = fc->H_inv_view_stride;
 	f.out_H = fc->out_H; f.outH_stride = fc->out_H_view_stride;
 	f.tile_scores = (float*)(ws + L.tile_scores);
+	f.only_flagged = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_prof_on)
 	{
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
 		(void)hipEventRecord(ev0, s);
 	}
-	if (fc->columns == 4) fr_launch_fisher<4>(p, f, s);
-	else fr_launch_fisher<11>(p, f, s);
+	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (FrRecA*)(ws + L.recA), (float*)(ws + L.recB), (uint8_t*)(ws + L.fallback), s);
+	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (FrRecA*)(ws + L.recA), (float*)(ws + L.recB), (uint8_t*)(ws + L.fallback), s);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);

@@ -44,11 +44,10 @@ FR_HD int fr_f2i(float f)
 // e^x as a fixed sequence of IEEE-754 binary32 operations (Cody-Waite reduction, degree-5 minimax
 // polynomial evaluated with fmaf, scaling by two exact powers of two).  <= 1 ulp.  The oracle uses the
 // same sequence, which is what makes forward parity bit-exact.
-FR_HD float fr_expf(float x)
+// Branch-free body of fr_expf: exact same operation sequence, valid for x in [-103.97, 88.72] and NaN (NaN in, NaN out);
+// anything else gives garbage without trapping, so kernels may evaluate it on lanes whose result they then discard.
+FR_HD float fr_expf_inrange(float x)
 {
-	if (!(x == x)) return x;
-	if (x > 88.72283905206835f) return INFINITY;
-	if (x < -103.97208f) return 0.0f;
 	float kf = rintf(x * 1.44269504088896341f);
 	float r = fmaf(kf, -0.693359375f, x);
 	r = fmaf(kf, 2.12194440e-4f, r);
@@ -64,6 +63,14 @@ FR_HD float fr_expf(float x)
 	int k1 = k >> 1;
 	int k2 = k - k1;
 	return (y * fr_as_f32((uint32_t)(k1 + 127) << 23)) * fr_as_f32((uint32_t)(k2 + 127) << 23);
+}
+
+FR_HD float fr_expf(float x)
+{
+	if (!(x == x)) return x;
+	if (x > 88.72283905206835f) return INFINITY;
+	if (x < -103.97208f) return 0.0f;
+	return fr_expf_inrange(x);
 }
 
 // ---- auxiliary.h ------------------------------------------------------------------------------

@@ -108,7 +108,7 @@ def load():
                                 _f32p, ctypes.c_int32] + [_f32p] * 9 + [ctypes.c_void_p]
     lib.fr_fisher_workspace_bytes.restype = ctypes.c_size_t
     lib.fr_fisher_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                                              ctypes.c_int64]
+                                              ctypes.c_int64, ctypes.c_int32]
     lib.fr_fisher_views.restype = ctypes.c_int
     lib.fr_fisher_views.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians),
                                     ctypes.POINTER(FisherCfg), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64,

@@ -64,9 +64,9 @@ def workspace_bytes(P, W, H, max_rendered):
 
 
 def workspace_layout(P, W, H, max_rendered):
-    names = ("depths", "means2D", "conic_opacity", "cov3D", "rgb", "clamped",
+    names = ("splat", "cov3D", "rgb", "clamped",
              "tile_count", "tile_offset", "tile_fill", "final_T", "n_contrib", "status", "keys")
-    out = (ctypes.c_size_t * 13)()
+    out = (ctypes.c_size_t * 11)()
     _lib.check(_lib.load().fr_workspace_layout(P, W, H, max_rendered, out), "fr_workspace_layout")
     return {n: int(out[i]) for i, n in enumerate(names)}
 
@@ -158,9 +158,8 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
     dL_dconic, dL_dopacity, dL_dcov3D = new(P, 2, 2), new(P, 1), new(P, 6)
     dL_dsh, dL_dscales, dL_drotations = torch.zeros((P, M, 3), dtype=torch.float32, device=dev), new(P, 3), new(P, 4)
     if P != 0:
-        # the kernels read opacity from the conic_opacity records of the geometry buffer; the pointer below only has
-        # to be non-null for argument validation
-        opac = _prep(opacities, dev) if opacities is not None else means3D
+        # the kernels read opacity from the splat records of the geometry buffer
+        opac = _prep(opacities, dev) if opacities is not None else None
         cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, False, bg, view, proj, cpos)
         g = _gaussians(means3D, colors, sh_t, opac, scales, rotations, cov3D_precomp)
         with torch.cuda.device(dev):
@@ -184,7 +183,7 @@ class FisherScorer:
     device status word when results are fetched (`fetch`), and the batch is re-run with a larger buffer.
     """
 
-    WORKSPACE_BUDGET = 6 << 30  # bytes of dense per-view geometry before views are processed in chunks
+    WORKSPACE_BUDGET = 24 << 30  # bytes of per-view workspace before views are processed in chunks
 
     def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
                  dL_dpix: float = 1e-3):
@@ -211,7 +210,7 @@ class FisherScorer:
         self.campos = _prep(raster_settings.campos, d)
         self._ws = None
         self._ws_key = None
-        self.per_view_capacity = max(self.P, 1 << 16)
+        self.per_view_capacity = max(int(0.75 * self.P), 1 << 16)
         self.cfg = _raster_cfg(self.P, self.H, self.W, raster_settings.tanfovx, raster_settings.tanfovy,
                                raster_settings.scale_modifier, raster_settings.sh_degree, 0,
                                raster_settings.prefiltered, self.bg, self.view, self.proj, self.campos)
@@ -219,13 +218,13 @@ class FisherScorer:
 
     # -- helpers -------------------------------------------------------------------------------------
     def max_views_per_launch(self):
-        per_view = max(self.P, 1) * 32 + self.per_view_capacity * 8
+        per_view = max(self.P, 1) * 32 + self.per_view_capacity * (8 + 32 + (208 if self.columns == 11 else 96))
         return max(1, int(self.WORKSPACE_BUDGET // per_view))
 
     def _workspace(self, V, max_rendered):
         key = (V, max_rendered)
         if self._ws is None or self._ws_key != key:
-            nbytes = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, V, max_rendered))
+            nbytes = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, V, max_rendered, self.columns))
             if nbytes == 0:
                 raise FisherRastError("fr_fisher_workspace_bytes: bad argument")
             if self._ws is None or self._ws.numel() < nbytes:

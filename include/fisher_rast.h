@@ -91,12 +91,12 @@ const char* fr_last_error(void);
 int fr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t out[3]);
 
 /* Byte offsets of the named sections inside the three buffers (for tests / debuggers).
- * geom:    [0] depths f32[P], [1] means2D f32[P,2], [2] conic_opacity f32[P,4], [3] cov3D f32[P,6],
- *          [4] rgb f32[P,3], [5] clamped u8[P,3]
- * image:   [6] tile_count u32[T], [7] tile_offset u32[T], [8] tile_fill u32[T], [9] final_T f32[HW],
- *          [10] n_contrib u32[HW], [11] status i32[4]
- * binning: [12] keys u64[R]  (sorted per tile: (depth_bits << 32) | gaussian_index) */
-int fr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t offsets[13]);
+ * geom:    [0] splat f32[P,8] = {mean2D.x, mean2D.y, conic.x, conic.y, conic.z, opacity, depth, pad} (valid where radii > 0),
+ *          [1] cov3D f32[P,6], [2] rgb f32[P,3], [3] clamped u8[P,3]
+ * image:   [4] tile_count u32[T], [5] tile_offset u32[T], [6] tile_fill u32[T], [7] final_T f32[HW],
+ *          [8] n_contrib u32[HW], [9] status i32[4]
+ * binning: [10] keys u64[R]  (sorted per tile: (depth_bits << 32) | gaussian_index) */
+int fr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t offsets[11]);
 
 int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, fr_stream_t stream);
@@ -137,7 +137,7 @@ typedef struct fr_fisher_cfg {
 	int32_t* out_num_rendered;  /* device [n_views]: tile instances per view, or null */
 } fr_fisher_cfg;
 
-size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered);
+size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);
 
 /* Scores n_views candidate poses in one batched launch sequence.  g->means3D are WORLD positions; each view's
  * camera-frame means are computed in-kernel from cfg_f->w2c and then rendered through cfg->viewmatrix/projmatrix

@@ -35,9 +35,10 @@ def hip_forward(dev, cam, means3D, opacities, colors_precomp=None, shs=None, sca
 
     def sec(buf, off, count, dt):
         return np.frombuffer(buf[off:off + count * np.dtype(dt).itemsize].tobytes(), dtype=dt)
-    out["depths"] = sec(g, L["depths"], P, np.float32)
-    out["means2D"] = sec(g, L["means2D"], 2 * P, np.float32).reshape(P, 2)
-    out["conic_opacity"] = sec(g, L["conic_opacity"], 4 * P, np.float32).reshape(P, 4)
+    splat = sec(g, L["splat"], 8 * P, np.float32).reshape(P, 8)
+    out["depths"] = splat[:, 6].copy()
+    out["means2D"] = splat[:, 0:2].copy()
+    out["conic_opacity"] = splat[:, 2:6].copy()
     out["cov3D"] = sec(g, L["cov3D"], 6 * P, np.float32).reshape(P, 6)
     out["rgb"] = sec(g, L["rgb"], 3 * P, np.float32).reshape(P, 3)
     out["clamped"] = sec(g, L["clamped"], 3 * P, np.uint8).reshape(P, 3)

@@ -37,16 +37,17 @@ def test_workspace_queries_are_host_only(lib):
     out = (ctypes.c_size_t * 3)()
     assert lib.fr_workspace_bytes(500000, 256, 256, 1 << 20, out) == 0
     geom, binning, img = int(out[0]), int(out[1]), int(out[2])
-    assert geom >= 500000 * (4 + 8 + 16 + 24 + 12 + 3) and binning >= (1 << 20) * 8 and img >= 256 * 256 * 8
-    off = (ctypes.c_size_t * 13)()
+    assert geom >= 500000 * (32 + 24 + 12 + 3) and binning >= (1 << 20) * 8 and img >= 256 * 256 * 8
+    off = (ctypes.c_size_t * 11)()
     assert lib.fr_workspace_layout(1000, 64, 48, 10, off) == 0
     o = [int(x) for x in off]
-    assert o[0] == 0 and all(x % 256 == 0 for x in o) and o[1] > o[0] and o[10] > o[9]
+    assert o[0] == 0 and all(x % 256 == 0 for x in o) and o[1] > o[0] and o[8] > o[7] and o[10] == 0
     assert lib.fr_workspace_bytes(-1, 256, 256, 0, out) == 1          # FR_EINVAL
     assert b"bad argument" in lib.fr_last_error()
-    n = int(lib.fr_fisher_workspace_bytes(500000, 256, 256, 64, 64 * 500000))
-    assert n >= 64 * 500000 * (4 + 4 + 8 + 16) + 64 * 500000 * 8
-    assert int(lib.fr_fisher_workspace_bytes(10, 0, 256, 1, 1)) == 0
+    n = int(lib.fr_fisher_workspace_bytes(500000, 256, 256, 64, 64 * 500000, 4))
+    assert n >= 64 * 500000 * (4 + 4 + 8 + 16) + 64 * 500000 * (8 + 32 + 96)
+    assert int(lib.fr_fisher_workspace_bytes(500000, 256, 256, 64, 64 * 500000, 11)) > n
+    assert int(lib.fr_fisher_workspace_bytes(10, 0, 256, 1, 1, 4)) == 0 and int(lib.fr_fisher_workspace_bytes(10, 16, 16, 1, 1, 5)) == 0
     assert int(lib.fr_knn_workspace_bytes(1000)) >= 1000 * 20
 
 
