@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "fr_math.h"
 #include "../../include/fisher_rast.h"
@@ -608,6 +609,7 @@ struct FrFisherArgs {
 	float* out_H; long long outH_stride;
 	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
 	const uint8_t* only_flagged; // [V][T] or null: when set, k_fisher_tile handles only the flagged tiles
+	int debug_mode;              // FR_DEBUG_MODE env (timing ablations only): 1 = k_fisher_tile_v2 stops after pass 1
 };
 
 template <int C, bool HAS_HINV, bool HAS_OUTH>
@@ -997,14 +999,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 {
 	constexpr int RB = FrRecBSize<C>::value;
 	constexpr int HO = (C == 11) ? 39 : 18;       // offset of H_inv inside a recB record
-	__shared__ float4 s_a0[FR_BATCH];
-	__shared__ float4 s_a1[FR_BATCH];
 	__shared__ uint16_t s_wl[4][FR_WCAP];
 	__shared__ float s_red[4];
 	__shared__ int s_ovf;
 
 	if (p.status[1]) return;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction; tell the compiler
 	uint32_t tile; int v;
 	fr_tile_of_block(p, tile, v);
 	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
@@ -1020,40 +1021,45 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		return;
 	}
 	if (tid == 0) s_ovf = 0;
+	__syncthreads();
 
-	// ---- pass 1 ----
+	// ---- pass 1: wave-private ----
+	// A wave streams the tile's recA records 64 at a time (one per lane, next chunk already in flight), keeps the ones
+	// whose conservative pixel box meets its 16x4 strip (one ballot), and walks the set bits in order, broadcasting a
+	// record from its owning lane with v_readlane.  No LDS staging, no workgroup barrier: a wave whose 64 pixels are
+	// all finished simply leaves.
 	bool done = !inside;
 	float T = 1.0f;
 	int last = 0;
 	int wcnt = 0;                                  // wave-uniform
-	for (uint32_t base = 0; base < n; base += FR_BATCH)
+	const uint32_t strip_lo = 4u * (uint32_t)wave, strip_hi = strip_lo + 3u;
+	const float4* ra = (const float4*)(recA + start);
+	float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+	if ((uint32_t)lane < n) { n0 = ra[2 * lane]; n1 = ra[2 * lane + 1]; }
+	for (uint32_t base = 0; base < n; base += 64)
 	{
-		if (__syncthreads_count(done) == FR_THREADS) break;
-		const uint32_t k = base + tid;
-		if (k < n)
+		const float4 q0 = n0, q1 = n1;
+		const uint32_t kn = base + 64 + lane;
+		if (kn < n) { n0 = ra[2 * (size_t)kn]; n1 = ra[2 * (size_t)kn + 1]; }
+		const uint32_t box = __float_as_uint(q1.w);
+		const uint32_t y0 = box & 0xffu, y1 = (box >> 8) & 0xffu;
+		const bool ov = (base + lane < n) && y0 <= strip_hi && y1 >= strip_lo && y0 <= y1;
+		unsigned long long todo = __ballot(ov);
+		while (todo)
 		{
-			const float4* src = (const float4*)(recA + start + k);
-			s_a0[tid] = src[0];
-			s_a1[tid] = src[1];
-		}
-		__syncthreads();
-		const int m = (int)min((uint32_t)FR_BATCH, n - base);
-		float4 a0n = s_a0[0], a1n = s_a1[0];
-		for (int j = 0; j < m; j++)
-		{
-			const float4 a0 = a0n, a1 = a1n;
-			if (j + 1 < m) { a0n = s_a0[j + 1]; a1n = s_a1[j + 1]; }   // next splat's record in flight during this one
-			// rows of this wave's 16x4 strip against the splat's conservative pixel box (wave-uniform skip)
-			const uint32_t box = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(a1.w));
-			if ((box & 0xffu) > (uint32_t)(4 * wave + 3) || ((box >> 8) & 0xffu) < (uint32_t)(4 * wave)) continue;
+			const int j = __builtin_ctzll(todo);
+			todo &= todo - 1ull;
+			const float x = fr_readlane_f(q0.x, j), y = fr_readlane_f(q0.y, j);
+			const float cx = fr_readlane_f(q0.z, j), cy = fr_readlane_f(q0.w, j), cz = fr_readlane_f(q1.x, j);
+			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(q1.z, j);
 			// forward.cu:338-357, predicated: same comparisons (written negated so that NaN behaves as in the reference)
-			const float dx = a0.x - pfx, dy = a0.y - pfy;
-			const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-			const bool pass = !done && !(power > 0.0f) && !(power < a1.z);
+			const float dx = x - pfx, dy = y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			const bool pass = !done && !(power > 0.0f) && !(power < thr);
 			if (__any(pass))
 			{
 				const float G = fr_expf_inrange(power);
-				const float alpha = fminf(0.99f, a1.y * G);
+				const float alpha = fminf(0.99f, o * G);
 				const bool ok = pass && !(alpha < 1.0f / 255.0f);
 				const float test_T = T * (1 - alpha);
 				const bool kill = ok && (test_T < 0.0001f);
@@ -1065,10 +1071,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 				{
 					// every lane stores the same value to the same address: no exec-mask juggling for a one-lane write
 					if (wcnt < FR_WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
-					wcnt++;
+					wcnt = __builtin_amdgcn_readfirstlane(wcnt + 1);
 				}
 			}
 		}
+		if (__all(done)) break;
 	}
 	if (lane == 0 && wcnt > FR_WCAP) s_ovf = 1;
 	__syncthreads();
@@ -1078,6 +1085,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		return;
 	}
 	if (tid == 0) fallback[vt] = 0;
+	if (f.debug_mode == 1) { if (tid == 0) f.tile_scores[vt] = (float)wcnt; return; }
 
 	// ---- pass 2: wave-private, back to front ----
 	FrPixState st;
@@ -1702,6 +1710,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.out_H = fc->out_H; f.outH_stride = fc->out_H_view_stride;
 	f.tile_scores = (float*)(ws + L.tile_scores);
 	f.only_flagged = nullptr;
+	{ const char* dm = getenv("FR_DEBUG_MODE"); f.debug_mode = dm ? atoi(dm) : 0; }
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_prof_on)
 	{
