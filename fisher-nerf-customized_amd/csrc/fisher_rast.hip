@@ -21,6 +21,7 @@
 // Wave64 mapping of a 16x16 tile: 256 threads = 4 waves, wave w owns the 16x4 pixel strip of rows 4w..4w+3, so a
 // small splat is seen by 1-2 waves and the others skip it with one ballot.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,7 +61,9 @@ static int fr_check_launch(const char* what)
 
 // ---------------------------------------------------------------------------------------------------------
 // Everything preprocess derives for one (view, Gaussian): one 32-byte record = one sector per gather.
-struct FrSplat { float x, y, cx, cy, cz, o, depth, pad; };
+// `ext` = two fp16 (rounded up): half extents (hx, hy) of the conservative pixel box in which alpha can reach 1/255
+// (negative hx: nowhere; +inf: unknown, treat as everywhere).
+struct FrSplat { float x, y, cx, cy, cz, o, depth; uint32_t ext; };
 
 struct FrParams {
 	int P, V, W, H;
@@ -104,6 +107,29 @@ __device__ __forceinline__ int wave_max_i(int v)
 __device__ __forceinline__ float fr_power_threshold(float opacity)
 {
 	return (opacity > 0.f) ? (-__logf(255.0f * opacity) - 0.01f) : INFINITY;
+}
+
+// Half extents (hx, hy), as two fp16 rounded up, of the region where `power >= thr` can hold, i.e. where alpha can reach
+// 1/255: the ellipse 1/2 d^T Q d <= -thr has half extents sqrt(-2 thr Sigma_xx), sqrt(-2 thr Sigma_yy), Sigma = Q^-1.
+// 1 % + 0.01 px of slack dwarfs the rounding of `power`.  hx < 0 encodes "no pixel", +inf "unknown".
+__device__ __forceinline__ uint32_t fr_alpha_extent(float cx, float cy, float cz, float opacity)
+{
+	const float thr = fr_power_threshold(opacity);
+	float hx = INFINITY, hy = INFINITY;
+	if (!(thr <= 0.f)) { hx = -1.f; hy = -1.f; }        // opacity <= 1/255 (or NaN): never reaches the alpha threshold
+	else
+	{
+		const float det = cx * cz - cy * cy;
+		if (det > 0.f && cx > 0.f && cz > 0.f)
+		{
+			const float tau2 = -2.0f * thr;
+			const float ex = sqrtf(tau2 * cz / det) * 1.01f + 0.01f;
+			const float ey = sqrtf(tau2 * cx / det) * 1.01f + 0.01f;
+			if (ex == ex && ey == ey) { hx = ex; hy = ey; }
+		}
+	}
+	const __half2 h = __halves2half2(__float2half_ru(hx), __float2half_ru(hy));
+	return *(const uint32_t*)&h;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -180,7 +206,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 			nvis++;
 			float4* dst = (float4*)(p.splat + vP + i);
 			dst[0] = make_float4(s.px, s.py, s.conx, s.cony);
-			dst[1] = make_float4(s.conz, p.opac[i], s.depth, 0.f);
+			dst[1] = make_float4(s.conz, p.opac[i], s.depth, __uint_as_float(fr_alpha_extent(s.conx, s.cony, s.conz, p.opac[i])));
 			if (p.colors == nullptr)
 			{
 				fr_f3 cp = { p.campos[0], p.campos[1], p.campos[2] };
@@ -841,9 +867,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 // ---------------------------------------------------------------------------------------------------------
 #define FR_WCAP 3840                 // per-wave list capacity (u16 positions): 30 KiB; LDS stays under the 40 KiB that 4 workgroups/CU allow
 
-struct FrRecA { float x, y, cx, cy, cz, o, thr; uint32_t box; };
-
-template <int C> struct FrRecBSize { static constexpr int value = (C == 11) ? 52 : 24; };
 
 // View-independent inputs of one Gaussian packed into one record: { mean[3], cov3D[6], rgb[3], (scale[3], rot[4]),
 // H_inv[C] } = 16 floats (64 B, one cache line) at C = 4, 32 floats at C = 11.  k_build_records then needs two gathers
@@ -885,120 +908,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 	for (int k = 0; k < PS / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
 }
 
-// Conservative tile-local pixel box of the pixels for which `power >= thr` can hold (i.e. alpha can reach 1/255):
-// the ellipse 1/2 d^T Q d <= -thr has half extents sqrt(-2 thr * Sigma_xx), sqrt(-2 thr * Sigma_yy), Sigma = Q^-1.
-// Packed as y0 | y1 << 8 | x0 << 16 | x1 << 24 (tile-local, inclusive); y0 > y1 means "no pixel of this tile".
-__device__ __forceinline__ uint32_t fr_pixel_box(float mx, float my, float cx, float cy, float cz, float thr, uint32_t px0, uint32_t py0)
-{
-	const uint32_t full = 0u | (15u << 8) | (0u << 16) | (15u << 24);
-	const uint32_t none = 1u | (0u << 8);
-	if (!(thr <= 0.f)) return none;              // opacity <= 1/255 (or NaN): never reaches the alpha threshold
-	const float det = cx * cz - cy * cy;
-	if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return full;
-	const float tau2 = -2.0f * thr;
-	const float hx = sqrtf(tau2 * cz / det) * 1.01f + 0.01f;
-	const float hy = sqrtf(tau2 * cx / det) * 1.01f + 0.01f;
-	if (!(hx == hx) || !(hy == hy)) return full;
-	const float fx0 = ceilf(mx - hx) - (float)px0, fx1 = floorf(mx + hx) - (float)px0;
-	const float fy0 = ceilf(my - hy) - (float)py0, fy1 = floorf(my + hy) - (float)py0;
-	if (fx1 < 0.f || fy1 < 0.f || fx0 > 15.f || fy0 > 15.f) return none;
-	const uint32_t x0 = (uint32_t)fmaxf(fx0, 0.f), x1 = (uint32_t)fminf(fx1, 15.f);
-	const uint32_t y0 = (uint32_t)fmaxf(fy0, 0.f), y1 = (uint32_t)fminf(fy1, 15.f);
-	return y0 | (y1 << 8) | (x0 << 16) | (x1 << 24);
-}
-
-template <int C, bool PER_VIEW_HINV>
-__global__ __launch_bounds__(FR_THREADS) void k_build_records(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
-                                                              FrRecA* __restrict__ recA, float* __restrict__ recB)
-{
-	constexpr int RB = FrRecBSize<C>::value;
-	constexpr int PS = FrPackSize<C>::value;
-	if (p.status[1]) return;
-	const int tid = threadIdx.x;
-	uint32_t tile; int v;
-	fr_tile_of_block(p, tile, v);
-	const size_t vt = (size_t)v * p.T + tile;
-	const size_t vP = (size_t)v * p.P;
-	const uint32_t n = p.tile_cnt[vt];
-	if (n == 0) return;
-	const size_t start = p.tile_off[vt];
-	const uint32_t px0 = (tile % p.gx) * FR_BLOCK_X, py0 = (tile / p.gx) * FR_BLOCK_Y;
-	float vm[16], pm[16], wm[12];
-#pragma unroll
-	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
-	const bool has_w2c = p.w2c != nullptr;
-	if (has_w2c)
-	{
-#pragma unroll
-		for (int k = 0; k < 12; k++) wm[k] = p.w2c[16 * (size_t)v + k];
-	}
-	for (uint32_t i = tid; i < n; i += FR_THREADS)
-	{
-		const size_t s = start + i;
-		const uint32_t id = (uint32_t)p.keys[s];
-		const float4* sp = (const float4*)(p.splat + vP + id);
-		const float4 q0 = sp[0], q1 = sp[1];
-		const float thr = fr_power_threshold(q1.y);
-		const uint32_t box = fr_pixel_box(q0.x, q0.y, q0.z, q0.w, q1.x, thr, px0, py0);
-		float4* da = (float4*)(recA + s);
-		da[0] = q0;
-		da[1] = make_float4(q1.x, q1.y, thr, __uint_as_float(box));
-		float g[PS];
-		const float4* pk = (const float4*)(packed + (size_t)id * PS);
-#pragma unroll
-		for (int k = 0; k < PS / 4; k++) { const float4 t4 = pk[k]; g[4 * k] = t4.x; g[4 * k + 1] = t4.y; g[4 * k + 2] = t4.z; g[4 * k + 3] = t4.w; }
-		float b[RB];
-#pragma unroll
-		for (int k = 0; k < RB; k++) b[k] = 0.f;
-		b[0] = g[9]; b[1] = g[10]; b[2] = g[11];
-		fr_f3 pw = { g[0], g[1], g[2] };
-		fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
-		float A[3][5];
-		float B[6][3];
-		fr_mean_jacobian(po, &g[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
-#pragma unroll
-		for (int r = 0; r < 3; r++)
-#pragma unroll
-			for (int c = 0; c < 5; c++) b[3 + r * 5 + c] = A[r][c];
-		int o = 18, go = 12;
-		if constexpr (C == 11)
-		{
-			fr_f3 sc = { g[12], g[13], g[14] };
-			fr_f4 q = { g[15], g[16], g[17], g[18] };
-			float Cm[7][3];
-			fr_scale_rot_jacobian(sc, p.mod, q, B, Cm);
-#pragma unroll
-			for (int r = 0; r < 7; r++)
-#pragma unroll
-				for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cm[r][c];
-			o = 39; go = 19;
-		}
-		if constexpr (PER_VIEW_HINV)
-		{
-			const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
-#pragma unroll
-			for (int c = 0; c < C; c++) b[o + c] = hp[c];
-		}
-		else
-		{
-#pragma unroll
-			for (int c = 0; c < C; c++) b[o + c] = g[go + c];
-		}
-		float4* dst = (float4*)(recB + s * RB);
-#pragma unroll
-		for (int k = 0; k < RB / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
-	}
-}
-
 __device__ __forceinline__ float fr_readlane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_float(__builtin_amdgcn_ds_bpermute(l << 2, __float_as_int(x))); }
 
 template <int C>
-__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const FrRecA* __restrict__ recA,
-                                                               const float* __restrict__ recB, uint8_t* __restrict__ fallback)
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
+                                                               uint8_t* __restrict__ fallback)
 {
-	constexpr int RB = FrRecBSize<C>::value;
-	constexpr int HO = (C == 11) ? 39 : 18;       // offset of H_inv inside a recB record
+	constexpr int PS = FrPackSize<C>::value;
+	constexpr int NB = (C == 11) ? 50 : 22;       // per-entry registers of pass 2: rgb[3], A[15], (Cm[21]), H_inv[C]
+	constexpr int HO = (C == 11) ? 39 : 18;       // offset of H_inv inside them
 	__shared__ uint16_t s_wl[4][FR_WCAP];
 	__shared__ float s_red[4];
 	__shared__ int s_ovf;
@@ -1013,8 +932,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
 	const float pfx = (float)pxx, pfy = (float)pxy;
 	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
 	const uint32_t n = p.tile_cnt[vt];
-	const size_t start = p.tile_off[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* splat = (const float4*)(p.splat + vP);
 	if (n > 65535u)
 	{
 		if (tid == 0) fallback[vt] = 1;
@@ -1024,26 +945,35 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	__syncthreads();
 
 	// ---- pass 1: wave-private ----
-	// A wave streams the tile's recA records 64 at a time (one per lane, next chunk already in flight), keeps the ones
-	// whose conservative pixel box meets its 16x4 strip (one ballot), and walks the set bits in order, broadcasting a
-	// record from its owning lane with v_readlane.  No LDS staging, no workgroup barrier: a wave whose 64 pixels are
-	// all finished simply leaves.
+	// A wave streams the tile's sorted keys 64 at a time (one per lane), gathers each splat's 32-byte record (next chunk
+	// already in flight), keeps the ones whose conservative alpha footprint meets its 16x4 strip (one ballot), and walks
+	// the set bits in order, broadcasting a record from its owning lane with v_readlane.  No LDS staging, no workgroup
+	// barrier: a wave whose 64 pixels are all finished simply leaves.
 	bool done = !inside;
 	float T = 1.0f;
 	int last = 0;
 	int wcnt = 0;                                  // wave-uniform
-	const uint32_t strip_lo = 4u * (uint32_t)wave, strip_hi = strip_lo + 3u;
-	const float4* ra = (const float4*)(recA + start);
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
 	float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
-	if ((uint32_t)lane < n) { n0 = ra[2 * lane]; n1 = ra[2 * lane + 1]; }
+	uint32_t idn = 0;
+	if ((uint32_t)lane < n)
+	{
+		idn = (uint32_t)gk[lane];
+		n0 = splat[2 * (size_t)idn]; n1 = splat[2 * (size_t)idn + 1];
+	}
+	uint32_t idnn = (64u + lane < n) ? (uint32_t)gk[64 + lane] : 0u;
 	for (uint32_t base = 0; base < n; base += 64)
 	{
 		const float4 q0 = n0, q1 = n1;
-		const uint32_t kn = base + 64 + lane;
-		if (kn < n) { n0 = ra[2 * (size_t)kn]; n1 = ra[2 * (size_t)kn + 1]; }
-		const uint32_t box = __float_as_uint(q1.w);
-		const uint32_t y0 = box & 0xffu, y1 = (box >> 8) & 0xffu;
-		const bool ov = (base + lane < n) && y0 <= strip_hi && y1 >= strip_lo && y0 <= y1;
+		if (base + 64 + lane < n) { n0 = splat[2 * (size_t)idnn]; n1 = splat[2 * (size_t)idnn + 1]; }
+		if (base + 128 + lane < n) idnn = (uint32_t)gk[base + 128 + lane];
+		const uint32_t eb = __float_as_uint(q1.w);
+		const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+		const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+		const bool ov = (base + lane < n) && hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi)
+		                && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
+		const float thr_l = fr_power_threshold(q1.y);
 		unsigned long long todo = __ballot(ov);
 		while (todo)
 		{
@@ -1051,7 +981,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			todo &= todo - 1ull;
 			const float x = fr_readlane_f(q0.x, j), y = fr_readlane_f(q0.y, j);
 			const float cx = fr_readlane_f(q0.z, j), cy = fr_readlane_f(q0.w, j), cz = fr_readlane_f(q1.x, j);
-			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(q1.z, j);
+			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(thr_l, j);
 			// forward.cu:338-357, predicated: same comparisons (written negated so that NaN behaves as in the reference)
 			const float dx = x - pfx, dy = y - pfy;
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
@@ -1088,6 +1018,20 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	if (f.debug_mode == 1) { if (tid == 0) f.tile_scores[vt] = (float)wcnt; return; }
 
 	// ---- pass 2: wave-private, back to front ----
+	// 64 list entries at a time, one per lane: the lane gathers its splat and the packed static record and pushes unit
+	// vectors through the Jacobian chain (backward.cu:335-475) -- once per entry, all 64 lanes busy.  Every lane then
+	// builds a 64-bit mask of the entries that can contribute to ITS pixel and walks its own set bits back to front,
+	// fetching the record it needs from the owning lane with ds_bpermute.
+	float vm[16], pm[16], wm[12];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const bool has_w2c = p.w2c != nullptr;
+	if (has_w2c)
+	{
+#pragma unroll
+		for (int k = 0; k < 12; k++) wm[k] = p.w2c[16 * (size_t)v + k];
+	}
+	const bool per_view_hinv = f.hinv_stride != 0;
 	FrPixState st;
 	st.T_final = inside ? T : 0.f;
 	st.T = st.T_final;
@@ -1106,21 +1050,52 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		// lane l owns list entry hi-1-l (descending position => bit order == back-to-front order)
 		int kk = 0x7fffffff;
 		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY;
-		float b[RB];
+		float b[NB];
 #pragma unroll
-		for (int q = 0; q < RB; q++) b[q] = 0.f;
+		for (int q = 0; q < NB; q++) b[q] = 0.f;
 		if (lane < m)
 		{
 			kk = (int)wl[hi - 1 - lane];
-			const float4* pa = (const float4*)(recA + start + kk);
-			const float4 a0 = pa[0], a1 = pa[1];
-			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = a1.z;
-			const float4* pb = (const float4*)(recB + (start + kk) * RB);
+			const uint32_t id = (uint32_t)gk[kk];
+			const float4 a0 = splat[2 * (size_t)id], a1 = splat[2 * (size_t)id + 1];
+			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = fr_power_threshold(a1.y);
+			float gsv[PS];
+			const float4* pk = (const float4*)(packed + (size_t)id * PS);
 #pragma unroll
-			for (int q = 0; q < RB / 4; q++)
+			for (int q = 0; q < PS / 4; q++) { const float4 t4 = pk[q]; gsv[4 * q] = t4.x; gsv[4 * q + 1] = t4.y; gsv[4 * q + 2] = t4.z; gsv[4 * q + 3] = t4.w; }
+			b[0] = gsv[9]; b[1] = gsv[10]; b[2] = gsv[11];
+			fr_f3 pw = { gsv[0], gsv[1], gsv[2] };
+			fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+			float A[3][5];
+			float B[6][3];
+			fr_mean_jacobian(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int c = 0; c < 5; c++) b[3 + r * 5 + c] = A[r][c];
+			int go = 12;
+			if constexpr (C == 11)
 			{
-				const float4 t4 = pb[q];
-				b[4 * q] = t4.x; b[4 * q + 1] = t4.y; b[4 * q + 2] = t4.z; b[4 * q + 3] = t4.w;
+				fr_f3 sc = { gsv[12], gsv[13], gsv[14] };
+				fr_f4 qr = { gsv[15], gsv[16], gsv[17], gsv[18] };
+				float Cm[7][3];
+				fr_scale_rot_jacobian(sc, p.mod, qr, B, Cm);
+#pragma unroll
+				for (int r = 0; r < 7; r++)
+#pragma unroll
+					for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cm[r][c];
+				go = 19;
+			}
+			if (per_view_hinv)
+			{
+				const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
+#pragma unroll
+				for (int c = 0; c < C; c++) b[HO + c] = hp[c];
+			}
+			else
+			{
+#pragma unroll
+				for (int c = 0; c < C; c++) b[HO + c] = gsv[go + c];
 			}
 		}
 		// mask of the chunk entries that MAY contribute to this lane's pixel (the conservative power threshold only;
@@ -1146,9 +1121,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
 			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
 			const float o = fr_bperm_f(ao, j);
-			float r[RB];
+			float r[NB];
 #pragma unroll
-			for (int q = 0; q < RB; q++) r[q] = fr_bperm_f(b[q], j);
+			for (int q = 0; q < NB; q++) r[q] = fr_bperm_f(b[q], j);
 			const float dx = x - pfx, dy = y - pfy;
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
 			const float G = fr_expf_inrange(power);
@@ -1607,7 +1582,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 
 // ---- fused Fisher scorer ---------------------------------------------------------------------------------
 struct FrFisherLayout {
-	size_t radii, splat, packed, big_list, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, recA, recB, total;
+	size_t radii, splat, packed, big_list, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
@@ -1628,8 +1603,6 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	const size_t R = (size_t)(max_rendered > 0 ? max_rendered : 1);
 	L.keys = o; o = fr_align(o + R * 8);
 	L.fallback = o; o = fr_align(o + (size_t)(V * T));
-	L.recA = o; o = fr_align(o + R * sizeof(FrRecA));
-	L.recB = o; o = fr_align(o + R * 4 * (size_t)(columns == 11 ? FrRecBSize<11>::value : FrRecBSize<4>::value));
 	L.total = o;
 	return L;
 }
@@ -1641,7 +1614,7 @@ extern "C" size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int
 }
 
 template <int C>
-static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, FrRecA* recA, float* recB, uint8_t* fallback, hipStream_t s)
+static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t* fallback, hipStream_t s)
 {
 	dim3 grid(p.T * p.V), block(FR_THREADS);
 	const bool hi = f.H_inv != nullptr, ho = f.out_H != nullptr;
@@ -1649,12 +1622,10 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, FrRecA*
 	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile<C, true, true>), grid, block, 0, s, p, f);
 	else if (hi)
 	{
-		// scores only: stream-ordered records + wave-private backward walk; flagged tiles are redone by the scan kernel
+		// scores only: wave-private passes over the sorted keys; flagged tiles are redone by the scan kernel
 		const bool per_view = f.hinv_stride != 0;
 		hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, per_view ? nullptr : f.H_inv, packed);
-		if (per_view) hipLaunchKernelGGL((k_build_records<C, true>), grid, block, 0, s, p, f, (const float*)packed, recA, recB);
-		else hipLaunchKernelGGL((k_build_records<C, false>), grid, block, 0, s, p, f, (const float*)packed, recA, recB);
-		hipLaunchKernelGGL((k_fisher_tile_v2<C>), grid, block, 0, s, p, f, (const FrRecA*)recA, (const float*)recB, fallback);
+		hipLaunchKernelGGL((k_fisher_tile_v2<C>), grid, block, 0, s, p, f, (const float*)packed, fallback);
 		f.only_flagged = fallback;
 		hipLaunchKernelGGL((k_fisher_tile<C, true, false>), grid, block, 0, s, p, f);
 	}
@@ -1717,8 +1688,8 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
 		(void)hipEventRecord(ev0, s);
 	}
-	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (FrRecA*)(ws + L.recA), (float*)(ws + L.recB), (uint8_t*)(ws + L.fallback), s);
-	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (FrRecA*)(ws + L.recA), (float*)(ws + L.recB), (uint8_t*)(ws + L.fallback), s);
+	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
+	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);

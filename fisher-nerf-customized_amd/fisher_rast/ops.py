@@ -183,7 +183,7 @@ class FisherScorer:
     device status word when results are fetched (`fetch`), and the batch is re-run with a larger buffer.
     """
 
-    WORKSPACE_BUDGET = 24 << 30  # bytes of per-view workspace before views are processed in chunks
+    WORKSPACE_BUDGET = 8 << 30  # bytes of per-view workspace before views are processed in chunks
 
     def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
                  dL_dpix: float = 1e-3):
@@ -218,7 +218,7 @@ class FisherScorer:
 
     # -- helpers -------------------------------------------------------------------------------------
     def max_views_per_launch(self):
-        per_view = max(self.P, 1) * 32 + self.per_view_capacity * (8 + 32 + (208 if self.columns == 11 else 96))
+        per_view = max(self.P, 1) * 36 + self.per_view_capacity * 8
         return max(1, int(self.WORKSPACE_BUDGET // per_view))
 
     def _workspace(self, V, max_rendered):

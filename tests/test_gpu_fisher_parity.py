@@ -156,7 +156,7 @@ def test_overflow_regrow_and_chunking(config1, gpu):
     base = sc.run(c["w2c"].to(gpu), H_inv=H_inv)["scores"].cpu()
     small = _scorer(c, gpu, 4)
     small.per_view_capacity = 64            # forces the device-side overflow flag and a re-run
-    small.WORKSPACE_BUDGET = 3 * (c["P"] * 32 + 64 * 136)   # and view chunking
+    small.WORKSPACE_BUDGET = 3 * (c["P"] * 36 + 64 * 8)   # and view chunking
     again = small.run(c["w2c"].to(gpu), H_inv=H_inv)
     assert torch.equal(again["scores"].cpu(), base)
     Ht2 = torch.zeros((c["P"], 4), device=gpu)
