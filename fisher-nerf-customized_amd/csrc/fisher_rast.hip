@@ -33,6 +33,7 @@
 #define FR_G_MAX 32                  // upper bound of Gaussians per thread in the per-Gaussian kernels (FrParams::G)
 #define FR_MAX_LDS_TILES 4096        // tile histogram kept in LDS up to 1024x1024 images
 #define FR_SORT_SMALL_KEYS 2048      // per-tile segments up to this size: 16 KiB of LDS, many workgroups per CU
+#define FR_SORT_MID_KEYS 4096        // listed segments up to this size: 32 KiB of LDS, 256 threads
 #define FR_SORT_BIG_KEYS 16384       // up to this size: 128 KiB of LDS, one workgroup per CU; beyond: global memory
 #define FR_BATCH 256                 // splats staged per round in the forward pass
 #define FR_BWD_BATCH 128             // splats staged per round in the backward passes
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_mark_visible(int P, const float*
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 {
-	__shared__ uint32_t hist[FR_MAX_LDS_TILES];
+	extern __shared__ uint32_t fr_dyn_lds[];     // T counters when T <= FR_MAX_LDS_TILES (sized at launch)
+	uint32_t* hist = fr_dyn_lds;
 	const int tid = threadIdx.x;
 	const int v = blockIdx.y;
 	const bool lds_hist = p.T <= FR_MAX_LDS_TILES;
@@ -322,8 +324,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 	// Block-aggregated slot claims: count this block's instances per tile in LDS, claim one contiguous range per
 	// non-empty tile with a single global atomic, then hand out slots inside the ranges with LDS atomics.  (The order
 	// of a tile's segment is irrelevant: k_sort_tiles sorts it and the keys are unique.)
-	__shared__ uint32_t s_cnt[FR_MAX_LDS_TILES];
-	__shared__ uint32_t s_base[FR_MAX_LDS_TILES];
+	extern __shared__ uint32_t fr_dyn_lds[];     // 2 T words when T <= FR_MAX_LDS_TILES (sized at launch)
+	uint32_t* s_cnt = fr_dyn_lds;
+	uint32_t* s_base = fr_dyn_lds + p.T;
 	if (p.status[1]) return;
 	const int tid = threadIdx.x;
 	const int v = blockIdx.y;
@@ -457,8 +460,30 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 	for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
 }
 
-// The few larger segments (listed by k_scan_tiles): 1024 threads, 128 KiB of LDS, grid-stride over the list; segments
-// beyond FR_SORT_BIG_KEYS run the same network on global memory (__syncthreads orders the workgroup's own accesses).
+// Larger segments are listed by k_scan_tiles and sorted by two grid-stride kernels over that list:
+//   k_sort_mid_tiles : FR_SORT_SMALL_KEYS < n <= FR_SORT_MID_KEYS, 256 threads, 32 KiB of LDS (several workgroups per CU)
+//   k_sort_big_tiles : n > FR_SORT_MID_KEYS, 1024 threads, 128 KiB of LDS; beyond FR_SORT_BIG_KEYS the same network runs
+//                      on global memory (__syncthreads orders the workgroup's own accesses).
+__global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
+{
+	if (p.status[1]) return;
+	__shared__ uint64_t skeys[FR_SORT_MID_KEYS];
+	const int tid = threadIdx.x;
+	const uint32_t count = p.big_list[0];
+	for (uint32_t b = blockIdx.x; b < count; b += gridDim.x)
+	{
+		const size_t vt = p.big_list[16 + b];
+		const uint32_t n = p.tile_cnt[vt];
+		if (n > (uint32_t)FR_SORT_MID_KEYS) continue;
+		uint64_t* gk = p.keys + p.tile_off[vt];
+		__syncthreads();
+		for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
+		__syncthreads();
+		fr_bitonic(skeys, n, tid, FR_THREADS);
+		for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+	}
+}
+
 __global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
 {
 	if (p.status[1]) return;
@@ -469,6 +494,7 @@ __global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
 	{
 		const size_t vt = p.big_list[16 + b];
 		const uint32_t n = p.tile_cnt[vt];
+		if (n <= (uint32_t)FR_SORT_MID_KEYS) continue;
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
 		if (n <= (uint32_t)FR_SORT_BIG_KEYS)
@@ -1470,16 +1496,20 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 	p.G = (int)(gwant < 1 ? 1 : (gwant > FR_G_MAX ? FR_G_MAX : gwant));
 	const int per_block = FR_THREADS * p.G;
 	dim3 gridP((P + per_block - 1) / per_block, p.V);
-	hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), 0, s, p);
+	const size_t hist_lds = p.T <= FR_MAX_LDS_TILES ? (size_t)p.T * 4 : 16;
+	hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
 	if ((rc = fr_check_launch("k_preprocess"))) return rc;
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
 	                   p.key_capacity, p.status, p.num_rendered, p.big_list);
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
-	hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 0, s, p);
+	hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
 	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
-	const int big_blocks = p.T * p.V < 512 ? p.T * p.V : 512;
+	const int mid_blocks = p.T * p.V < 2048 ? p.T * p.V : 2048;
+	hipLaunchKernelGGL(k_sort_mid_tiles, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p);
+	if ((rc = fr_check_launch("k_sort_mid_tiles"))) return rc;
+	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
 	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
 	return FR_OK;
