@@ -623,7 +623,8 @@ struct FrPixState {
 	float last_alpha;
 };
 
-__device__ __forceinline__ void fr_pair_backward(FrPixState& s, float alpha, float G, float dx, float dy,
+template <bool FAST_RCP>
+__device__ __forceinline__ void fr_pair_backward_t(FrPixState& s, float alpha, float G, float dx, float dy,
                                                  float cx, float cy, float cz, float o,
                                                  float c0, float c1, float c2, float g0, float g1, float g2,
                                                  float bg_dot, float ddelx_dx, float ddely_dy,
@@ -631,7 +632,9 @@ __device__ __forceinline__ void fr_pair_backward(FrPixState& s, float alpha, flo
                                                  float& wcol, float& gop)
 {
 #pragma clang fp contract(fast)
-	s.T = s.T / (1.f - alpha);
+	// 1/(1-alpha): IEEE division in the generic backward; one v_rcp_f32 (1 ulp) in the scorer, whose tolerance is 1e-4
+	const float inv = FAST_RCP ? __builtin_amdgcn_rcpf(1.f - alpha) : 1.f / (1.f - alpha);
+	s.T = FAST_RCP ? s.T * inv : s.T / (1.f - alpha);
 	wcol = alpha * s.T;
 	float dL_dalpha;
 	s.accum0 = s.last_alpha * s.lastc0 + (1.f - s.last_alpha) * s.accum0; s.lastc0 = c0;
@@ -640,7 +643,7 @@ __device__ __forceinline__ void fr_pair_backward(FrPixState& s, float alpha, flo
 	dL_dalpha = (c0 - s.accum0) * g0 + (c1 - s.accum1) * g1 + (c2 - s.accum2) * g2;
 	dL_dalpha *= s.T;
 	s.last_alpha = alpha;
-	dL_dalpha += (-s.T_final / (1.f - alpha)) * bg_dot;
+	if (bg_dot != 0.f) dL_dalpha += FAST_RCP ? (-s.T_final * inv) * bg_dot : (-s.T_final / (1.f - alpha)) * bg_dot;
 	const float dL_dG = o * dL_dalpha;
 	const float gdx = G * dx, gdy = G * dy;
 	const float dG_ddelx = -gdx * cx - gdy * cy;
@@ -651,6 +654,42 @@ __device__ __forceinline__ void fr_pair_backward(FrPixState& s, float alpha, flo
 	qy = -0.5f * gdx * dy * dL_dG;
 	qw = -0.5f * gdy * dy * dL_dG;
 	gop = G * dL_dalpha;
+}
+
+__device__ __forceinline__ void fr_pair_backward(FrPixState& s, float alpha, float G, float dx, float dy,
+                                                 float cx, float cy, float cz, float o,
+                                                 float c0, float c1, float c2, float g0, float g1, float g2,
+                                                 float bg_dot, float ddelx_dx, float ddely_dy,
+                                                 float& m2x, float& m2y, float& qx, float& qy, float& qw,
+                                                 float& wcol, float& gop)
+{
+	fr_pair_backward_t<false>(s, alpha, G, dx, dy, cx, cy, cz, o, c0, c1, c2, g0, g1, g2, bg_dot, ddelx_dx, ddely_dy,
+	                          m2x, m2y, qx, qy, qw, wcol, gop);
+}
+
+// 64x64 bit-matrix transpose across the 64 lanes of a wave: lane i holds row i in, row i of the transpose out
+// (out[i] bit j == in[j] bit i).  Six block-swap rounds, each one 64-bit exchange with the partner lane.
+template <int SFT>
+__device__ __forceinline__ unsigned long long fr_transpose_round(unsigned long long x, int lane)
+{
+	// m: bits whose index has (index & SFT) == 0
+	constexpr unsigned long long m = SFT == 32 ? 0x00000000FFFFFFFFull : SFT == 16 ? 0x0000FFFF0000FFFFull :
+	                                 SFT == 8 ? 0x00FF00FF00FF00FFull : SFT == 4 ? 0x0F0F0F0F0F0F0F0Full :
+	                                 SFT == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+	const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)x, SFT, 64);
+	const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), SFT, 64);
+	const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+	return (lane & SFT) ? ((x & ~m) | ((other & ~m) >> SFT)) : ((x & m) | ((other & m) << SFT));
+}
+__device__ __forceinline__ unsigned long long fr_wave_transpose64(unsigned long long x, int lane)
+{
+	x = fr_transpose_round<32>(x, lane);
+	x = fr_transpose_round<16>(x, lane);
+	x = fr_transpose_round<8>(x, lane);
+	x = fr_transpose_round<4>(x, lane);
+	x = fr_transpose_round<2>(x, lane);
+	x = fr_transpose_round<1>(x, lane);
+	return x;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1075,7 +1114,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		const int m = min(64, hi);
 		// lane l owns list entry hi-1-l (descending position => bit order == back-to-front order)
 		int kk = 0x7fffffff;
-		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY;
+		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY, ahx = -1.f, ahy = -1.f;
 		float b[NB];
 #pragma unroll
 		for (int q = 0; q < NB; q++) b[q] = 0.f;
@@ -1085,6 +1124,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const uint32_t id = (uint32_t)gk[kk];
 			const float4 a0 = splat[2 * (size_t)id], a1 = splat[2 * (size_t)id + 1];
 			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = fr_power_threshold(a1.y);
+			{
+				const uint32_t eb = __float_as_uint(a1.w);
+				ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+				ahy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			}
 			float gsv[PS];
 			const float4* pk = (const float4*)(packed + (size_t)id * PS);
 #pragma unroll
@@ -1124,29 +1168,39 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 				for (int c = 0; c < C; c++) b[HO + c] = gsv[go + c];
 			}
 		}
-		// mask of the chunk entries that MAY contribute to this lane's pixel (the conservative power threshold only;
-		// the exact alpha test is repeated in the walk, on the one record the lane then holds)
-		unsigned long long mask = 0ull;
-		for (int j = 0; j < m; j++)
+		// Candidate mask.  Entry-major first: the lane that owns entry e marks the pixels of this wave's 16x4 strip that
+		// lie inside the entry's conservative alpha footprint (bit = 16*row + column = the pixel's lane).  A 64x64 bit
+		// transpose then hands every pixel-lane the set of entries that may touch it -- ~120 instructions per chunk
+		// instead of 64 broadcast pair tests.  The exact tests (position < last, power window, alpha >= 1/255) are done
+		// in the walk on the one record the lane holds there.
+		unsigned long long emask = 0ull;
+		if (lane < m && ahx >= 0.f)
 		{
-			const int kj = __builtin_amdgcn_readlane(kk, j);
-			const float x = fr_readlane_f(ax, j), y = fr_readlane_f(ay, j);
-			const float cx = fr_readlane_f(acx, j), cy = fr_readlane_f(acy, j), cz = fr_readlane_f(acz, j);
-			const float thr = fr_readlane_f(athr, j);
-			const float dx = x - pfx, dy = y - pfy;
-			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-			const bool act = inside && (kj < last) && !(power > 0.0f) && !(power < thr);
-			mask |= act ? (1ull << j) : 0ull;
+			const float c0f = fmaxf(ceilf(ax - ahx) - tile_x0, 0.f), c1f = fminf(floorf(ax + ahx) - tile_x0, 15.f);
+			const float r0f = fmaxf(ceilf(ay - ahy) - strip_lo, 0.f), r1f = fminf(floorf(ay + ahy) - strip_lo, 3.f);
+			if (c0f <= c1f && r0f <= r1f)
+			{
+				const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f, r0 = (unsigned)r0f, r1 = (unsigned)r1f;
+				const unsigned long long cols = (unsigned long long)(((2u << c1) - 1u) & ~((1u << c0) - 1u));
+#pragma unroll
+				for (unsigned r = 0; r < 4; r++)
+					emask |= (r >= r0 && r <= r1) ? (cols << (16 * r)) : 0ull;
+			}
 		}
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		// chunk positions are descending: nothing to do for a pixel whose last contributor lies in front of the chunk
+		const int kmin = __builtin_amdgcn_readlane(kk, m - 1);
+		if (!(inside && last > kmin)) mask = 0ull;
 		// every lane walks its own set bits; the loop is wave-uniform so that all lanes take part in the bpermutes
 		while (__any(mask != 0ull))
 		{
 			bool has = mask != 0ull;
 			const int j = has ? (__ffsll((long long)mask) - 1) : 0;
 			mask &= mask - 1ull;
+			const int kj = __builtin_amdgcn_ds_bpermute(j << 2, kk);
 			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
 			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
-			const float o = fr_bperm_f(ao, j);
+			const float o = fr_bperm_f(ao, j), thr = fr_bperm_f(athr, j);
 			float r[NB];
 #pragma unroll
 			for (int q = 0; q < NB; q++) r[q] = fr_bperm_f(b[q], j);
@@ -1154,12 +1208,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
 			const float G = fr_expf_inrange(power);
 			const float alpha = fminf(0.99f, o * G);
-			has = has && !(alpha < 1.0f / 255.0f);
+			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);
 			if (has)
 			{
 				float m2x, m2y, qx, qy, qw, wcol, gop;
-				fr_pair_backward(st, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
-				                 m2x, m2y, qx, qy, qw, wcol, gop);
+				fr_pair_backward_t<true>(st, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
+				                         m2x, m2y, qx, qy, qw, wcol, gop);
 #pragma unroll
 				for (int q = 0; q < 3; q++)
 				{

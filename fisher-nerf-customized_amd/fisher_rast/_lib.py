@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfisher_rast.so")
+# FISHER_RAST_SO lets an A/B benchmark load another build of the same ABI; the default is the in-tree library
+SO_PATH = os.environ.get("FISHER_RAST_SO", os.path.join(_HERE, "libfisher_rast.so"))
 
 FR_OK, FR_EINVAL, FR_ELAUNCH, FR_ENOSPACE = 0, 1, 2, 3
 
