@@ -976,12 +976,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 __device__ __forceinline__ float fr_readlane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_float(__builtin_amdgcn_ds_bpermute(l << 2, __float_as_int(x))); }
 
-template <int C>
+// HAS_HINV: weighted score per view (pose_eval).  HAS_OUTH: cur_H materialised / accumulated (compute_Hessian,
+// compute_H_train): the pixel-lanes of a wave add their squared leaves into a 64-entry LDS accumulator of the chunk
+// (ds_add_f32), and the lane that owns an entry then issues ONE global atomic per column for the whole wave -- the
+// reference issues one per pixel per column.
+template <int C, bool HAS_HINV, bool HAS_OUTH>
 __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
                                                                uint8_t* __restrict__ fallback)
 {
+	__shared__ float s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];
 	constexpr int PS = FrPackSize<C>::value;
-	constexpr int NB = (C == 11) ? 50 : 22;       // per-entry registers of pass 2: rgb[3], A[15], (Cm[21]), H_inv[C]
+	constexpr int NB = ((C == 11) ? 39 : 18) + (HAS_HINV ? C : 0);   // per-entry registers of pass 2: rgb[3], A[15], (Cm[21]), [H_inv[C]]
 	constexpr int HO = (C == 11) ? 39 : 18;       // offset of H_inv inside them
 	__shared__ uint16_t s_wl[4][FR_WCAP];
 	__shared__ float s_red[4];
@@ -1018,6 +1023,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	float T = 1.0f;
 	int last = 0;
 	int wcnt = 0;                                  // wave-uniform
+#ifdef FR_LOOPSTATS
+	int dbg_p1 = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0;   // -DFR_LOOPSTATS + FR_DEBUG_MODE >= 2: loop-trip counters
+#define FR_STAT(x) x
+#else
+#define FR_STAT(x)
+#endif
 	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
 	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
 	float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
@@ -1044,6 +1055,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		{
 			const int j = __builtin_ctzll(todo);
 			todo &= todo - 1ull;
+			FR_STAT(dbg_p1++;)
 			const float x = fr_readlane_f(q0.x, j), y = fr_readlane_f(q0.y, j);
 			const float cx = fr_readlane_f(q0.z, j), cy = fr_readlane_f(q0.w, j), cz = fr_readlane_f(q1.x, j);
 			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(thr_l, j);
@@ -1112,16 +1124,24 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	for (int hi = wcnt; hi > 0; hi -= 64)
 	{
 		const int m = min(64, hi);
+		FR_STAT(dbg_chunks++;)
 		// lane l owns list entry hi-1-l (descending position => bit order == back-to-front order)
-		int kk = 0x7fffffff;
+		int kk = -1;                  // unused lanes sort behind every real position (positions are descending in the lane index)
 		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY, ahx = -1.f, ahy = -1.f;
 		float b[NB];
 #pragma unroll
 		for (int q = 0; q < NB; q++) b[q] = 0.f;
+		uint32_t my_id = 0;
+		if constexpr (HAS_OUTH)
+		{
+#pragma unroll
+			for (int c = 0; c < C; c++) s_acc[wave][c][lane] = 0.f;
+		}
 		if (lane < m)
 		{
 			kk = (int)wl[hi - 1 - lane];
 			const uint32_t id = (uint32_t)gk[kk];
+			my_id = id;
 			const float4 a0 = splat[2 * (size_t)id], a1 = splat[2 * (size_t)id + 1];
 			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = fr_power_threshold(a1.y);
 			{
@@ -1156,17 +1176,21 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 					for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cm[r][c];
 				go = 19;
 			}
-			if (per_view_hinv)
+			if constexpr (HAS_HINV)
 			{
-				const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
+				if (per_view_hinv)
+				{
+					const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
 #pragma unroll
-				for (int c = 0; c < C; c++) b[HO + c] = hp[c];
-			}
-			else
-			{
+					for (int c = 0; c < C; c++) b[HO + c] = hp[c];
+				}
+				else
+				{
 #pragma unroll
-				for (int c = 0; c < C; c++) b[HO + c] = gsv[go + c];
+					for (int c = 0; c < C; c++) b[HO + c] = gsv[go + c];
+				}
 			}
+			(void)go;
 		}
 		// Candidate mask.  Entry-major first: the lane that owns entry e marks the pixels of this wave's 16x4 strip that
 		// lie inside the entry's conservative alpha footprint (bit = 16*row + column = the pixel's lane).  A 64x64 bit
@@ -1176,25 +1200,54 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		unsigned long long emask = 0ull;
 		if (lane < m && ahx >= 0.f)
 		{
-			const float c0f = fmaxf(ceilf(ax - ahx) - tile_x0, 0.f), c1f = fminf(floorf(ax + ahx) - tile_x0, 15.f);
-			const float r0f = fmaxf(ceilf(ay - ahy) - strip_lo, 0.f), r1f = fminf(floorf(ay + ahy) - strip_lo, 3.f);
-			if (c0f <= c1f && r0f <= r1f)
-			{
-				const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f, r0 = (unsigned)r0f, r1 = (unsigned)r1f;
-				const unsigned long long cols = (unsigned long long)(((2u << c1) - 1u) & ~((1u << c0) - 1u));
+			// Row by row: power(dx, dy) >= thr  <=>  cx dx^2 + 2 cy dy dx + (cz dy^2 + 2 thr) <= 0, an interval in dx
+			// (d = mean - pixel).  Widened by 1 % + 0.01 px, so it stays a superset of the exact test done in the walk.
+			const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
 #pragma unroll
-				for (unsigned r = 0; r < 4; r++)
-					emask |= (r >= r0 && r <= r1) ? (cols << (16 * r)) : 0ull;
+			for (unsigned r = 0; r < 4; r++)
+			{
+				const float dy = ay - (strip_lo + (float)r);
+				float lo = ax - ahx, hi2 = ax + ahx;                  // box fallback (unknown / degenerate conic)
+				bool any_px = fabsf(dy) <= ahy;
+				if (quad_ok)
+				{
+					const float hb = acy * dy;                         // b / 2
+					const float cq = acz * dy * dy + 2.0f * athr;
+					const float disc = hb * hb - acx * cq;             // (b^2 - 4ac) / 4
+					any_px = any_px && (disc >= 0.f);
+					const float sq = sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
+					const float dlo = (-hb - sq) / acx, dhi = (-hb + sq) / acx;   // dx in [dlo, dhi]
+					lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;               // pixel x = mean.x - dx
+				}
+				const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, 15.f);
+				if (any_px && c0f <= c1f)
+				{
+					const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f;
+					const unsigned long long cols = (unsigned long long)(((2u << c1) - 1u) & ~((1u << c0) - 1u));
+					emask |= cols << (16 * r);
+				}
 			}
 		}
 		unsigned long long mask = fr_wave_transpose64(emask, lane);
-		// chunk positions are descending: nothing to do for a pixel whose last contributor lies in front of the chunk
-		const int kmin = __builtin_amdgcn_readlane(kk, m - 1);
-		if (!(inside && last > kmin)) mask = 0ull;
+		// Chunk positions are descending, so the entries at or behind this pixel's last contributor are the FIRST t bits:
+		// t = #{ j : k_j >= last } by a 6-step binary search over the chunk (ds_bpermute), then cleared at once.
+		{
+			int t = 0;
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1)
+			{
+				const int probe = t + step - 1;                       // 0-based index of the element that would be included
+				const int kp = __builtin_amdgcn_ds_bpermute((probe & 63) << 2, kk);
+				if (probe < 64 && kp >= last) t += step;
+			}
+			mask = (t >= 64) ? 0ull : (mask & ~((1ull << t) - 1ull));
+			if (!inside) mask = 0ull;
+		}
 		// every lane walks its own set bits; the loop is wave-uniform so that all lanes take part in the bpermutes
 		while (__any(mask != 0ull))
 		{
 			bool has = mask != 0ull;
+			FR_STAT(dbg_steps++;)
 			const int j = has ? (__ffsll((long long)mask) - 1) : 0;
 			mask &= mask - 1ull;
 			const int kj = __builtin_amdgcn_ds_bpermute(j << 2, kk);
@@ -1208,33 +1261,65 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
 			const float G = fr_expf_inrange(power);
 			const float alpha = fminf(0.99f, o * G);
-			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);
+			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);   // exact tests
+			FR_STAT(dbg_hits += (int)__popcll(__ballot(has));)
 			if (has)
 			{
 				float m2x, m2y, qx, qy, qw, wcol, gop;
 				fr_pair_backward_t<true>(st, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
 				                         m2x, m2y, qx, qy, qw, wcol, gop);
+				float leaf2[C];
 #pragma unroll
 				for (int q = 0; q < 3; q++)
 				{
 					const float l = r[3 + q * 5 + 0] * m2x + r[3 + q * 5 + 1] * m2y + r[3 + q * 5 + 2] * qx
 					              + r[3 + q * 5 + 3] * qy + r[3 + q * 5 + 4] * qw;
-					score += (l * l) * r[HO + q];
+					leaf2[q] = l * l;
 				}
-				score += (gop * gop) * r[HO + 3];
+				leaf2[3] = gop * gop;
 				if constexpr (C == 11)
 				{
 #pragma unroll
 					for (int q = 0; q < 7; q++)
 					{
 						const float l = r[18 + q * 3 + 0] * qx + r[18 + q * 3 + 1] * qy + r[18 + q * 3 + 2] * qw;
-						score += (l * l) * r[HO + 4 + q];
+						leaf2[4 + q] = l * l;
 					}
+				}
+				if constexpr (HAS_HINV)
+				{
+#pragma unroll
+					for (int c = 0; c < C; c++) score += leaf2[c] * r[HO + c];
+				}
+				if constexpr (HAS_OUTH)
+				{
+#pragma unroll
+					for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], leaf2[c]);
+				}
+			}
+		}
+		if constexpr (HAS_OUTH)
+		{
+			// wave-private LDS: the accumulators are complete once this wave's own ds_add instructions have retired
+			__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+			if (lane < m)
+			{
+				float* dst = f.out_H + (size_t)v * f.outH_stride + (size_t)my_id * C;
+#pragma unroll
+				for (int c = 0; c < C; c++)
+				{
+					const float a = s_acc[wave][c][lane];
+					if (a != 0.f) atomicAdd(dst + c, a);
 				}
 			}
 		}
 	}
-	const float ws = wave_sum(score);
+	if constexpr (!HAS_HINV) { (void)score; return; }
+	float ws = wave_sum(score);
+#ifdef FR_LOOPSTATS
+	if (f.debug_mode >= 2)
+		ws = f.debug_mode == 2 ? (float)dbg_p1 : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_steps : f.debug_mode == 5 ? (float)dbg_hits : (float)wcnt;
+#endif
 	if (lane == 0) s_red[wave] = ws;
 	__syncthreads();
 	if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
@@ -1702,17 +1787,17 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t
 {
 	dim3 grid(p.T * p.V), block(FR_THREADS);
 	const bool hi = f.H_inv != nullptr, ho = f.out_H != nullptr;
+	const bool per_view = hi && f.hinv_stride != 0;
+	// wave-private passes over the sorted keys; tiles whose lists do not fit the LDS index are flagged ...
 	f.only_flagged = nullptr;
+	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed);
+	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile_v2<C, true, true>), grid, block, 0, s, p, f, (const float*)packed, fallback);
+	else if (hi) hipLaunchKernelGGL((k_fisher_tile_v2<C, true, false>), grid, block, 0, s, p, f, (const float*)packed, fallback);
+	else hipLaunchKernelGGL((k_fisher_tile_v2<C, false, true>), grid, block, 0, s, p, f, (const float*)packed, fallback);
+	// ... and redone by the scan kernel
+	f.only_flagged = fallback;
 	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile<C, true, true>), grid, block, 0, s, p, f);
-	else if (hi)
-	{
-		// scores only: wave-private passes over the sorted keys; flagged tiles are redone by the scan kernel
-		const bool per_view = f.hinv_stride != 0;
-		hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, per_view ? nullptr : f.H_inv, packed);
-		hipLaunchKernelGGL((k_fisher_tile_v2<C>), grid, block, 0, s, p, f, (const float*)packed, fallback);
-		f.only_flagged = fallback;
-		hipLaunchKernelGGL((k_fisher_tile<C, true, false>), grid, block, 0, s, p, f);
-	}
+	else if (hi) hipLaunchKernelGGL((k_fisher_tile<C, true, false>), grid, block, 0, s, p, f);
 	else hipLaunchKernelGGL((k_fisher_tile<C, false, true>), grid, block, 0, s, p, f);
 }
 
