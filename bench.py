@@ -148,16 +148,16 @@ def main():
         views_per_s = V * world * a.steps / dt
         R = float(num_rendered.sum())          # tile instances of this rank's V views
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        # algorithmic bytes of ONE k_fisher_tile launch (DESIGN.md "k_fisher_tile"): per tile instance the transmittance
-        # pass reads key 8 + xy 8 + conic_opacity 16 and the backward pass reads those again + rgb 12 + mean 12 +
-        # cov3D 24 + H_inv 4*C; plus one partial score per tile.
-        kern_bytes = R * (32 + 32 + 12 + 12 + 24 + 4 * C) + 4.0 * V * T
+        # algorithmic bytes of ONE k_fisher_tile_v2 launch: per tile instance pass 1 reads the key (8)
+        # and the 32-byte splat record; pass 2 reads those again plus the packed static record (mean, cov3D, rgb, H_inv:
+        # 64 B at C = 4, 128 B at C = 11); plus one partial score per (view, tile).
+        kern_bytes = R * ((8 + 32) + (8 + 32) + (64 if C == 4 else 128)) + 4.0 * V * T
         ach = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
         # whole-path algorithmic bytes per view, SURVEY.md 8(d)
         B_view = (12 * P + 44 * vis_count.mean() + 24 * num_rendered.mean() + 40 * num_rendered.mean() +
                   40 * num_rendered.mean() + 24 * W * H + 8 * W * H + 4 * C * P)
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile.json")
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v2.json")
         if os.path.exists(pmc_file):
             try:
                 pm = json.load(open(pmc_file))
@@ -175,7 +175,7 @@ def main():
                        "tile_instances_per_view": float(num_rendered.mean()), "visible_per_view": float(vis_count.mean()),
                        "parallelism": f"views sharded over {world} GPU(s), scores all-gathered" if world > 1 else "1 GPU"},
             "fisher_scores_per_s": views_per_s * P * C,
-            "roofline": {"bound": "hbm", "kernel": "k_fisher_tile", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_fisher_tile_v2", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
                          "kernel_share_of_step": (kern_ms / (1e3 * dt / a.steps)) if kern_ms == kern_ms else None},

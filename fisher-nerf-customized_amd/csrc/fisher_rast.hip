@@ -1791,9 +1791,21 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t
 	// wave-private passes over the sorted keys; tiles whose lists do not fit the LDS index are flagged ...
 	f.only_flagged = nullptr;
 	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed);
+	// measurement hook: events around the dominant kernel only, on the stream it runs on
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (g_prof_on)
+	{
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, s);
+	}
 	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile_v2<C, true, true>), grid, block, 0, s, p, f, (const float*)packed, fallback);
 	else if (hi) hipLaunchKernelGGL((k_fisher_tile_v2<C, true, false>), grid, block, 0, s, p, f, (const float*)packed, fallback);
 	else hipLaunchKernelGGL((k_fisher_tile_v2<C, false, true>), grid, block, 0, s, p, f, (const float*)packed, fallback);
+	if (g_prof_on)
+	{
+		(void)hipEventRecord(ev1, s);
+		g_prof_events.push_back(std::make_pair(ev0, ev1));
+	}
 	// ... and redone by the scan kernel
 	f.only_flagged = fallback;
 	if (hi && ho) hipLaunchKernelGGL((k_fisher_tile<C, true, true>), grid, block, 0, s, p, f);
@@ -1851,19 +1863,9 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.tile_scores = (float*)(ws + L.tile_scores);
 	f.only_flagged = nullptr;
 	{ const char* dm = getenv("FR_DEBUG_MODE"); f.debug_mode = dm ? atoi(dm) : 0; }
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	if (g_prof_on)
-	{
-		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
-		(void)hipEventRecord(ev0, s);
-	}
 	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
 	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
-	if (g_prof_on)
-	{
-		(void)hipEventRecord(ev1, s);
-		g_prof_events.push_back(std::make_pair(ev0, ev1));
-	}
+
 	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
 	if (fc->out_scores)
 	{

@@ -445,6 +445,9 @@ FR_HD void fr_mean_jacobian(fr_f3 mean, const float* cov3D, const float* view, c
 	float Mp[3][2];
 	fr_proj_jacobian(mean, proj, Mp);
 	for (int k = 0; k < 3; k++) { A[k][0] = Mp[k][0]; A[k][1] = Mp[k][1]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
 	for (int j = 0; j < 3; j++)
 	{
 		fr_f3 dm; float dcov[6];
@@ -459,6 +462,9 @@ FR_HD void fr_mean_jacobian(fr_f3 mean, const float* cov3D, const float* view, c
 // Jacobian of (dL_dscale[3], dL_drot[4]) w.r.t. (cx, cy, cw), given B = d(dL_dcov3D)/d(cx,cy,cw)
 FR_HD void fr_scale_rot_jacobian(fr_f3 scale, float mod, fr_f4 rot, const float B[6][3], float Cm[7][3])
 {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
 	for (int j = 0; j < 3; j++)
 	{
 		float dcov[6];

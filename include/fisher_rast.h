@@ -158,7 +158,7 @@ int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, si
 /* ---- measurement hooks (not part of the reference surface) ------------------------------------------ */
 
 /* When enabled, every fr_fisher_views call records a pair of HIP events around its dominant kernel
- * (k_fisher_tile) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
+ * (k_fisher_tile_v2) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
 int fr_profile_enable(int on);
 /* Waits for the recorded events and writes up to max_n per-launch durations in milliseconds; returns the count
  * (or -1 on a HIP error).  This is the only entry point that blocks. */
