@@ -1361,10 +1361,14 @@ __device__ __forceinline__ float fr_powi(float x, int power)
 	return powf(x, (float)power);
 }
 
-template <bool HAS_SR>
+// HAS_SH: colours came from spherical harmonics; the per-pixel colour gradient then also moves the mean through the
+// view direction (backward.cu:127-138): mean += Dm * dL_dcolor with a per-splat 3x3 Dm staged next to A.  dL_dsh itself
+// is finished per Gaussian by k_finish_sh.
+template <bool HAS_SR, bool HAS_SH>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdArgs b)
 {
-	constexpr int NA = 15 + 18 + (HAS_SR ? 21 : 0);
+	constexpr int DMO = 15 + 18 + (HAS_SR ? 21 : 0);   // offset of Dm inside the staged coefficients
+	constexpr int NA = DMO + (HAS_SH ? 9 : 0);
 	constexpr int NL = 18 + (HAS_SR ? 7 : 0);   // leaves: m2(2) conic(3) col(3) op(1) mean(3) cov(6) [scale(3) rot(4)]
 	__shared__ fr_f2 s_xy[FR_BWD_BATCH];
 	__shared__ fr_f4 s_co[FR_BWD_BATCH];
@@ -1445,6 +1449,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 #pragma unroll
 					for (int c = 0; c < 3; c++) s_A[33 + r * 3 + c][tid] = Cm[r][c];
 			}
+			if constexpr (HAS_SH)
+			{
+				// backward.cu:1067: the fused kernel offsets the SH pointer by M*id FLOATS (not vec3s); reproduced as is
+				fr_f3 cp = { p.campos[0], p.campos[1], p.campos[2] };
+				float coef[16];
+				float Dm[3][3];
+				fr_sh_backward_jacobian(p.D, po, cp, p.shs + (size_t)p.M * id, p.clamped + 3 * (size_t)id, coef, Dm);
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+#pragma unroll
+					for (int c = 0; c < 3; c++) s_A[DMO + r * 3 + c][tid] = Dm[r][c];
+			}
 		}
 		__syncthreads();
 		for (int j = 0; j < m; j++)
@@ -1472,8 +1488,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 				leaf[8] = fr_powi(gop, power);
 #pragma unroll
 				for (int r = 0; r < 3; r++)
-					leaf[9 + r] = fr_powi(s_A[r * 5 + 0][j] * m2x + s_A[r * 5 + 1][j] * m2y + s_A[r * 5 + 2][j] * qx
-					                      + s_A[r * 5 + 3][j] * qy + s_A[r * 5 + 4][j] * qw, power);
+				{
+					float lm = s_A[r * 5 + 0][j] * m2x + s_A[r * 5 + 1][j] * m2y + s_A[r * 5 + 2][j] * qx
+					         + s_A[r * 5 + 3][j] * qy + s_A[r * 5 + 4][j] * qw;
+					if constexpr (HAS_SH)
+						lm += s_A[DMO + r * 3 + 0][j] * (wcol * g0) + s_A[DMO + r * 3 + 1][j] * (wcol * g1) + s_A[DMO + r * 3 + 2][j] * (wcol * g2);
+					leaf[9 + r] = fr_powi(lm, power);
+				}
 #pragma unroll
 				for (int r = 0; r < 6; r++)
 					leaf[12 + r] = fr_powi(s_A[15 + r * 3 + 0][j] * qx + s_A[15 + r * 3 + 1][j] * qy + s_A[15 + r * 3 + 2][j] * qw, power);
@@ -1507,6 +1528,31 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 			}
 		}
 		remaining -= m;
+	}
+}
+
+// dL_dsh, finished per Gaussian: every per-pixel dL_dsh[k][c] is coef_k(dir) * clamp_mask_c * dL_dcolor_c, so its sum of
+// grad_power-th powers is coef_k^power * mask_c * (accumulated dL_dcolors[c]).  Reference quirk kept: nothing is
+// accumulated when the SH degree is 0 (backward.cu:1117).
+__global__ __launch_bounds__(FR_THREADS) void k_finish_sh(FrParams p, const float* __restrict__ dL_dcolors, int power,
+                                                          float* __restrict__ dL_dsh)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= p.P || p.D <= 0 || p.radii[i] <= 0) return;
+	fr_f3 pos = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+	fr_f3 cp = { p.campos[0], p.campos[1], p.campos[2] };
+	float coef[16];
+	float Dm[3][3];
+	fr_sh_backward_jacobian(p.D, pos, cp, p.shs + (size_t)p.M * i, p.clamped + 3 * (size_t)i, coef, Dm);
+	const int nsh = (p.D + 1) * (p.D + 1);
+	for (int k = 0; k < nsh; k++)
+	{
+		const float ck = fr_powi(coef[k], power);
+		for (int c = 0; c < 3; c++)
+		{
+			const float mask = p.clamped[3 * (size_t)i + c] ? 0.f : 1.f;
+			dL_dsh[((size_t)i * p.M + k) * 3 + c] = ck * mask * dL_dcolors[3 * (size_t)i + c];
+		}
 	}
 }
 
@@ -1716,8 +1762,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	if (!geom_ws || !binning_ws || !image_ws || !radii || !dL_dout_color || !dL_dmeans2D || !dL_dcolors || !dL_dopacity ||
 	    !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_dconic)
 		return fr_fail(FR_EINVAL, "fr_backward: null pointer");
-	if (g->shs)
-		return fr_fail(FR_EINVAL, "fr_backward: spherical-harmonics colours are forward-only in this build (the reference's callers always pass colors_precomp)");
+	if (g->shs && !dL_dsh) return fr_fail(FR_EINVAL, "fr_backward: dL_dsh is null although SHs were given");
 	(void)hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * 4, s);
 	(void)hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * 4, s);
 	(void)hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s);
@@ -1742,11 +1787,19 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	b.power = power;
 	b.dL_dmean2D = dL_dmeans2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolors = dL_dcolors;
 	b.dL_dmean3D = dL_dmeans3D; b.dL_dcov3D = dL_dcov3D; b.dL_dscale = dL_dscales; b.dL_drot = dL_drotations;
-	if (g->scales)
-		hipLaunchKernelGGL(k_backward_tile<true>, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, b);
-	else
-		hipLaunchKernelGGL(k_backward_tile<false>, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, b);
-	return fr_check_launch("k_backward_tile");
+	const bool sr = g->scales != nullptr, sh = g->shs != nullptr;
+	dim3 grid(p.T, 1), block(FR_THREADS);
+	if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
+	else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
+	else if (sh) hipLaunchKernelGGL((k_backward_tile<false, true>), grid, block, 0, s, p, b);
+	else hipLaunchKernelGGL((k_backward_tile<false, false>), grid, block, 0, s, p, b);
+	if ((rc = fr_check_launch("k_backward_tile"))) return rc;
+	if (sh)
+	{
+		hipLaunchKernelGGL(k_finish_sh, dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (const float*)dL_dcolors, (int)power, dL_dsh);
+		if ((rc = fr_check_launch("k_finish_sh"))) return rc;
+	}
+	return FR_OK;
 }
 
 // ---- fused Fisher scorer ---------------------------------------------------------------------------------

@@ -181,3 +181,49 @@ def test_argument_errors(gpu):
                               1.0, e, eye, eye, 1.0, 1.0, 32, 32, e, 0, torch.zeros(3, device=gpu), False)
     with pytest.raises(FisherRastError):   # CPU tensors: no CPU path
         ops.mark_visible(torch.zeros((4, 3)), torch.eye(4), torch.eye(4))
+
+
+@pytest.mark.parametrize("deg", [0, 1, 3])
+@pytest.mark.parametrize("power", [1, 2])
+def test_sh_backward(gpu, oracle, deg, power):
+    """SH colours: dL_dsh, and the extra mean gradient through the view direction (backward.cu:20-139), including the
+    reference's quirks (no dL_dsh when the degree is 0, backward.cu:1117; float-offset SH pointer, 1067)."""
+    W, H = 96, 64
+    P = 2500
+    sc = random_scene(P, 31 + deg, scale=0.07)
+    M = 16
+    shs = np.random.default_rng(deg).normal(scale=2.0, size=(P, M, 3)).astype(np.float32)   # large enough to clamp some colours
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), _pose(0.1))._replace(sh_degree=deg, campos=np.array([0.3, -0.2, -0.4], np.float32))
+    want = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], shs=shs, scales=sc["scales"], rotations=sc["rotations"])
+    got = hip_forward(gpu, cam, sc["means3D"], sc["opacities"], shs=shs, scales=sc["scales"], rotations=sc["rotations"])
+    assert want["clamped"].any()
+    dL = np.random.default_rng(7).normal(size=(3, H, W)).astype(np.float32) if power == 1 else np.full((3, H, W), 1e-3, np.float32)
+    gw = oracle.rasterize_backward(cam, want, dL, power)
+    gg = hip_backward(gpu, cam, got, dL, power)
+    fl = 2e-5 if power == 1 else 1e-7
+    for n in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dsh"):
+        assert_close(gg[n], gw[n], 1e-4, f"deg{deg}/p{power}/{n}", atol_frac=fl)
+    assert gg["dL_dsh"].shape == (P, M, 3)
+    if deg == 0:
+        assert not gg["dL_dsh"].any()
+    else:
+        assert np.abs(gg["dL_dsh"][:, : (deg + 1) ** 2]).max() > 0 and not gg["dL_dsh"][:, (deg + 1) ** 2:].any()
+
+
+def test_autograd_front_end_with_shs(gpu):
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings
+    P = 800
+    sc = random_scene(P, 40)
+    t = {k: torch.tensor(v, device=gpu, requires_grad=True) for k, v in sc.items() if k != "colors"}
+    shs = torch.randn((P, 4, 3), device=gpu, requires_grad=True)
+    eye = torch.eye(4, device=gpu)
+    proj = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1.0001, 1], [0, 0, -0.01, 0]], dtype=torch.float32, device=gpu)
+    rs = GaussianRasterizationSettings(64, 64, 1.0, 1.0, torch.zeros(3, device=gpu), 1.0, eye, proj, 1, torch.zeros(3, device=gpu), False)
+    m2d = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    im, radii, depth = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"].reshape(-1, 1), shs=shs,
+                                              scales=t["scales"], rotations=t["rotations"])
+    assert im.shape == (3, 64, 64) and radii.dtype == torch.int32 and depth.shape == (1, 64, 64)
+    im.sum().backward()
+    assert shs.grad.shape == (P, 4, 3) and float(shs.grad.abs().sum()) > 0
+    assert t["means3D"].grad.shape == (P, 3) and m2d.grad.shape == (P, 3)
+    assert torch.isfinite(t["scales"].grad).all() and torch.isfinite(t["rotations"].grad).all()
