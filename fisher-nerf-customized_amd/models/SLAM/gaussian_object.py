@@ -1,11 +1,100 @@
-"""`GaussianObjectSLAM`: the object-aware variant's Fisher surface (models/SLAM/gaussian_object.py:1541-1551,
-1591-1617, 1940-2045): 11 Fisher columns [mean xyz | opacity | scale xyz | rot rxyz], optional random Gaussians
-appended with colour 0.5, `compute_Hessian(..., return_pose=True)` -> (cur_H, eye(6), vis_count)."""
+"""`GaussianObjectSLAM`: the object-aware variant's Fisher surface (models/SLAM/gaussian_object.py of the reference):
+  compute_Hessian / compute_H_train / pose_eval (1541-1551, 1591-1617, 1940-2045): 11 Fisher columns
+      [mean xyz | opacity | scale xyz | rot rxyz], optional random Gaussians appended with colour 0.5,
+      `compute_Hessian(..., return_pose=True)` -> (cur_H, eye(6), vis_count)  -- batched through fr_fisher_views;
+  estimate_diag_JtJ_simple (2049-2109), compute_H_train_popgs (1552-1569), pose_eval_popgs (1619-1662),
+  topt_score_from_diags / dopt_score_from_diags (1706-1719): the POp-GS "simple diag" criteria.  These are NOT linear in
+      cur_H and need K backward passes with random upstream gradients on one forward, so they run through the drop-in
+      autograd rasteriser exactly as the reference does (forward once, `backward(gradient=z, retain_graph=...)` K times on
+      the power-2 rasteriser, squares of those gradients averaged -- the reference's own quirk).
+"""
+import torch
+import torch.nn.functional as F
+
+from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 from models.SLAM.gaussian import FisherOps, GaussianSLAM
 
 
 class ObjectFisherOps(FisherOps):
     FISHER_COLUMNS = 11
+
+    @torch.enable_grad()
+    def estimate_diag_JtJ_simple(self, w2c, K: int = 4, zs=None):
+        """Returns (diag / K, vis_count), diag flat as [means(3N) | opacity(N) | rot(4N) | scale(3N)].
+        `zs` (optional list of K [3,H,W] tensors) replaces the reference's `torch.randn_like(im)` draws."""
+        dev = self._device()
+        w2c = self._as_w2c(w2c)
+        p = self.params
+        with torch.no_grad():
+            pts = p['means3D']
+            pts4 = torch.cat([pts, torch.ones(pts.shape[0], 1, device=dev, dtype=torch.float32)], dim=1)
+            transformed_pts = (w2c @ pts4.T).T[:, :3].contiguous()
+            rgb_colors = p['rgb_colors']
+            rotations = F.normalize(p['unnorm_rotations'])
+            opacities = torch.sigmoid(p['logit_opacities'])
+            scales = torch.exp(p['log_scales'])
+            if scales.shape[-1] == 1:
+                scales = torch.tile(scales, (1, 3))
+        rendervar = {
+            'means3D': transformed_pts.requires_grad_(True),
+            'opacities': opacities.detach().clone().requires_grad_(True),
+            'rotations': rotations.detach().clone().requires_grad_(True),
+            'scales': scales.detach().clone().requires_grad_(True),
+            'colors_precomp': rgb_colors.detach(),
+            'means2D': torch.zeros_like(transformed_pts, requires_grad=True, device=dev),
+        }
+        im, radius, _ = Renderer(raster_settings=self.cam, backward_power=2)(**rendervar)
+        vis_count = int((radius > 0).sum().item())
+        diag_accum = None
+        for k in range(K):
+            z = torch.randn_like(im) if zs is None else zs[k].to(dev)
+            for v in rendervar.values():
+                if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None:
+                    v.grad.zero_()
+            im.backward(gradient=z, retain_graph=(k < K - 1))
+            g = torch.cat([rendervar['means3D'].grad.detach().reshape(-1), rendervar['opacities'].grad.detach().reshape(-1),
+                           rendervar['rotations'].grad.detach().reshape(-1), rendervar['scales'].grad.detach().reshape(-1)], dim=0)
+            contrib = g * g
+            diag_accum = contrib if diag_accum is None else diag_accum + contrib
+        return diag_accum / float(K), vis_count
+
+    def compute_H_train_popgs(self, K: int = 4):
+        H = None
+        for kf in self.keyframe_list:
+            cur, _ = self.estimate_diag_JtJ_simple(kf['est_w2c'], K=K)
+            H = cur if H is None else H + cur
+        if H is None:
+            raise RuntimeError("No keyframes available for POP-GS prior.")
+        return H
+
+    @staticmethod
+    def topt_score_from_diags(H_train_diag, JtJ_diag_pi, lam: float = 1e-6):
+        """T-opt (to maximise): - sum_j 1 / (H_train_j + JtJ_j + lam)."""
+        Hpi = H_train_diag + JtJ_diag_pi + lam
+        return -torch.sum(1.0 / torch.clamp(Hpi, min=1e-12))
+
+    @staticmethod
+    def dopt_score_from_diags(H_train_diag, JtJ_diag_pi, lam: float = 1e-6):
+        """D-opt (to maximise): sum_j log(H_train_j + JtJ_j + lam) - sum_j log(H_train_j + lam)."""
+        Hm = H_train_diag + lam
+        Hpi = Hm + JtJ_diag_pi
+        return torch.sum(torch.log(torch.clamp(Hpi, min=1e-12))) - torch.sum(torch.log(torch.clamp(Hm, min=1e-12)))
+
+    def pose_eval_popgs(self, poses, random_gaussian_params=None, criterion: str = "topt", K: int = 4, lam: float = 1e-6):
+        H_train_diag = self.compute_H_train_popgs(K=K)
+        scores, c2ws = [], []
+        for c2w in poses:
+            c2w = self._as_w2c(c2w)
+            cur_diag, _ = self.estimate_diag_JtJ_simple(torch.linalg.inv(c2w), K=K)
+            if criterion.lower() == "topt":
+                s = self.topt_score_from_diags(H_train_diag, cur_diag, lam=lam)
+            elif criterion.lower() == "dopt":
+                s = self.dopt_score_from_diags(H_train_diag, cur_diag, lam=lam)
+            else:
+                raise ValueError("criterion must be 'topt' or 'dopt'")
+            scores.append(s)
+            c2ws.append(c2w)
+        return torch.tensor(scores), torch.stack(c2ws)
 
 
 class GaussianObjectSLAM(ObjectFisherOps, GaussianSLAM):

@@ -177,3 +177,40 @@ def test_per_view_weights_path_eval(config1, gpu):
     for v in range(V):
         one = sc.run(c["w2c"][v:v + 1].to(gpu), H_inv=Hi[v])["scores"].cpu().numpy()
         assert one[0] == got[v]
+
+
+def test_popgs_diag_estimator(config1, gpu, oracle):
+    """estimate_diag_JtJ_simple (gaussian_object.py:2049-2109) with the random upstream gradients supplied:
+    diag = mean_k (power-2 gradient under z_k)^2, layout [means | opacity | rot | scale]."""
+    import models.gaussian_slam as mgs
+    c = config1
+    slam = mgs.GaussianObjectSLAM(params=c["params"], intrinsics=c["K"], width=c["W"], height=c["H"], device=gpu)
+    K = 2
+    g = torch.Generator().manual_seed(5)
+    zs = [torch.randn((3, c["H"], c["W"]), generator=g) for _ in range(K)]
+    w2c = torch.linalg.inv(c["c2w"][1].to(gpu))
+    diag, vis = slam.estimate_diag_JtJ_simple(w2c, K=K, zs=zs)
+    P = c["P"]
+    assert diag.shape == (P * 11,)
+    # oracle on the very same device-side render variables
+    from models.SLAM.utils.slam_helpers import transformed_params2rendervar
+    pts = slam.params["means3D"]
+    tp = (w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3]
+    n = {k: v.detach().cpu().numpy() for k, v in transformed_params2rendervar(slam.params, tp).items()}
+    fw = oracle.rasterize_forward(c["ocam"], n["means3D"], n["opacities"], colors_precomp=n["colors_precomp"], scales=n["scales"], rotations=n["rotations"])
+    acc = 0.0
+    for z in zs:
+        gz = oracle.rasterize_backward(c["ocam"], fw, z.numpy(), 2)
+        gcat = np.concatenate([gz["dL_dmeans3D"].reshape(-1), gz["dL_dopacity"].reshape(-1), gz["dL_drotations"].reshape(-1), gz["dL_dscales"].reshape(-1)]).astype(np.float64)
+        acc = acc + gcat ** 2
+    want = acc / K
+    assert vis == int((fw["radii"] > 0).sum())
+    assert_close(diag.cpu().numpy(), want, 2e-4, "diag_JtJ", atol_frac=1e-7)
+    for kf in c["kf_w2c"][:2]:
+        slam.add_keyframe(kf)
+    Ht = slam.compute_H_train_popgs(K=1)
+    t = slam.topt_score_from_diags(Ht, diag, lam=1e-6)
+    d = slam.dopt_score_from_diags(Ht, diag, lam=1e-6)
+    assert torch.isfinite(t) and torch.isfinite(d) and float(d) >= 0.0 and float(t) < 0.0
+    scores, c2ws = slam.pose_eval_popgs([p.to(gpu) for p in c["c2w"][:2]], criterion="dopt", K=1)
+    assert scores.shape == (2,) and c2ws.shape == (2, 4, 4)
