@@ -1350,6 +1350,8 @@ struct FrBwdArgs {
 	const float* final_T; const uint32_t* n_contrib;
 	const float* colors;         // colors_precomp or rgb from SH
 	int power;
+	const uint8_t* only_flagged; // [T] or null: k_backward_tile handles only the flagged tiles
+	int u_only;                  // 1: accumulate only (mean2D, conic, colour, opacity) -- the other leaves come from k_backward_finish
 	float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolors; float* dL_dmean3D;
 	float* dL_dcov3D; float* dL_dscale; float* dL_drot;
 };
@@ -1384,6 +1386,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
 	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
 	const float pfx = (float)pxx, pfy = (float)pxy;
+	if (b.only_flagged && !b.only_flagged[tile]) return;
 	const uint32_t n = p.tile_cnt[tile];
 	const uint64_t* gk = p.keys + p.tile_off[tile];
 	const size_t HW = (size_t)p.H * p.W;
@@ -1512,7 +1515,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 				const float s = wave_sum(leaf[c]);
 				if (lane == c) mine = s;
 			}
-			if (lane < NL && mine != 0.f)
+			if (lane < (b.u_only ? 9 : NL) && mine != 0.f)
 			{
 				const size_t id = s_id[j];
 				float* dst;
@@ -1528,6 +1531,287 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 			}
 		}
 		remaining -= m;
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Gradient (grad_power == 1) backward of ONE view, second generation.
+//
+// For power 1 every leaf is J * (sum over pixels of u), so the tile kernel only has to sum the per-pixel vector
+// u = (dL_dmean2D.xy, dL_dconic.xyw, dL_dcolor.rgb, dL_dopacity) per splat, and the Jacobian chain runs once per Gaussian in
+// k_backward_finish (the classic split of the upstream 3DGS backward; renderCUDAFused re-derives it per pixel).
+// k_backward_lin_tile has k_fisher_tile_v2's structure: wave-private transmittance pass that records which splats touched the
+// strip, then a back-to-front walk in which every lane follows its own pixel's contributors; the 9 sums of a 64-entry
+// chunk live in LDS (ds_add_f32) and leave as one global atomic per entry and component.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, FrBwdArgs b, uint8_t* __restrict__ fallback)
+{
+	__shared__ uint16_t s_wl[4][FR_WCAP];
+	__shared__ float s_acc[4][9][64];
+	__shared__ int s_ovf;
+
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const uint32_t n = p.tile_cnt[tile];
+	const uint64_t* gk = p.keys + p.tile_off[tile];
+	const float4* splat = (const float4*)p.splat;
+	if (n > 65535u)
+	{
+		if (tid == 0) fallback[tile] = 1;
+		return;
+	}
+	if (tid == 0) s_ovf = 0;
+	__syncthreads();
+
+	// ---- pass 1 (same as k_fisher_tile_v2): transmittance, last contributor, per-wave list ----
+	bool done = !inside;
+	float T = 1.0f;
+	int last = 0;
+	int wcnt = 0;
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+	float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+	uint32_t idn = 0;
+	if ((uint32_t)lane < n)
+	{
+		idn = (uint32_t)gk[lane];
+		n0 = splat[2 * (size_t)idn]; n1 = splat[2 * (size_t)idn + 1];
+	}
+	uint32_t idnn = (64u + lane < n) ? (uint32_t)gk[64 + lane] : 0u;
+	for (uint32_t base = 0; base < n; base += 64)
+	{
+		const float4 q0 = n0, q1 = n1;
+		if (base + 64 + lane < n) { n0 = splat[2 * (size_t)idnn]; n1 = splat[2 * (size_t)idnn + 1]; }
+		if (base + 128 + lane < n) idnn = (uint32_t)gk[base + 128 + lane];
+		const uint32_t eb = __float_as_uint(q1.w);
+		const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+		const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+		const bool ov = (base + lane < n) && hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi)
+		                && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
+		const float thr_l = fr_power_threshold(q1.y);
+		unsigned long long todo = __ballot(ov);
+		while (todo)
+		{
+			const int j = __builtin_ctzll(todo);
+			todo &= todo - 1ull;
+			const float x = fr_readlane_f(q0.x, j), y = fr_readlane_f(q0.y, j);
+			const float cx = fr_readlane_f(q0.z, j), cy = fr_readlane_f(q0.w, j), cz = fr_readlane_f(q1.x, j);
+			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(thr_l, j);
+			const float dx = x - pfx, dy = y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			const bool pass = !done && !(power > 0.0f) && !(power < thr);
+			if (__any(pass))
+			{
+				const float G = fr_expf_inrange(power);
+				const float alpha = fminf(0.99f, o * G);
+				const bool ok = pass && !(alpha < 1.0f / 255.0f);
+				const float test_T = T * (1 - alpha);
+				const bool kill = ok && (test_T < 0.0001f);
+				const bool contrib = ok && !kill;
+				done = done || kill;
+				T = contrib ? test_T : T;
+				last = contrib ? ((int)base + j + 1) : last;
+				if (__any(contrib))
+				{
+					if (wcnt < FR_WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
+					wcnt = __builtin_amdgcn_readfirstlane(wcnt + 1);
+				}
+			}
+		}
+		if (__all(done)) break;
+	}
+	if (lane == 0 && wcnt > FR_WCAP) s_ovf = 1;
+	__syncthreads();
+	if (s_ovf)
+	{
+		if (tid == 0) fallback[tile] = 1;
+		return;
+	}
+	if (tid == 0) fallback[tile] = 0;
+
+	// ---- pass 2: back to front, sums of u per list entry ----
+	const size_t HW = (size_t)p.H * p.W;
+	const size_t pix = (size_t)p.W * pxy + pxx;
+	FrPixState st;
+	st.T_final = inside ? T : 0.f;
+	st.T = st.T_final;
+	st.accum0 = st.accum1 = st.accum2 = 0.f;
+	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
+	st.last_alpha = 0.f;
+	float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+	if (inside) { g0 = b.dL_dpix[pix]; g1 = b.dL_dpix[HW + pix]; g2 = b.dL_dpix[2 * HW + pix]; }
+	const float bg_dot = p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2;
+	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+	const uint16_t* wl = s_wl[wave];
+
+	for (int hi = wcnt; hi > 0; hi -= 64)
+	{
+		const int m = min(64, hi);
+		int kk = -1;
+		uint32_t my_id = 0;
+		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY, ahx = -1.f, ahy = -1.f;
+		float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+		for (int c = 0; c < 9; c++) s_acc[wave][c][lane] = 0.f;
+		if (lane < m)
+		{
+			kk = (int)wl[hi - 1 - lane];
+			my_id = (uint32_t)gk[kk];
+			const float4 a0 = splat[2 * (size_t)my_id], a1 = splat[2 * (size_t)my_id + 1];
+			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = fr_power_threshold(a1.y);
+			const uint32_t eb = __float_as_uint(a1.w);
+			ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			ahy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			c0 = b.colors[3 * (size_t)my_id]; c1 = b.colors[3 * (size_t)my_id + 1]; c2 = b.colors[3 * (size_t)my_id + 2];
+		}
+		unsigned long long emask = 0ull;
+		if (lane < m && ahx >= 0.f)
+		{
+			const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
+#pragma unroll
+			for (unsigned r = 0; r < 4; r++)
+			{
+				const float dy = ay - (strip_lo + (float)r);
+				float lo = ax - ahx, hi2 = ax + ahx;
+				bool any_px = fabsf(dy) <= ahy;
+				if (quad_ok)
+				{
+					const float hb = acy * dy;
+					const float cq = acz * dy * dy + 2.0f * athr;
+					const float disc = hb * hb - acx * cq;
+					any_px = any_px && (disc >= 0.f);
+					const float sq = sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
+					const float dlo = (-hb - sq) / acx, dhi = (-hb + sq) / acx;
+					lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;
+				}
+				const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, 15.f);
+				if (any_px && c0f <= c1f)
+				{
+					const unsigned cc0 = (unsigned)c0f, cc1 = (unsigned)c1f;
+					const unsigned long long cols = (unsigned long long)(((2u << cc1) - 1u) & ~((1u << cc0) - 1u));
+					emask |= cols << (16 * r);
+				}
+			}
+		}
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		{
+			int t = 0;
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1)
+			{
+				const int probe = t + step - 1;
+				const int kp = __builtin_amdgcn_ds_bpermute((probe & 63) << 2, kk);
+				if (probe < 64 && kp >= last) t += step;
+			}
+			mask = (t >= 64) ? 0ull : (mask & ~((1ull << t) - 1ull));
+			if (!inside) mask = 0ull;
+		}
+		while (__any(mask != 0ull))
+		{
+			bool has = mask != 0ull;
+			const int j = has ? (__ffsll((long long)mask) - 1) : 0;
+			mask &= mask - 1ull;
+			const int kj = __builtin_amdgcn_ds_bpermute(j << 2, kk);
+			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
+			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
+			const float o = fr_bperm_f(ao, j), thr = fr_bperm_f(athr, j);
+			const float r0 = fr_bperm_f(c0, j), r1 = fr_bperm_f(c1, j), r2 = fr_bperm_f(c2, j);
+			const float dx = x - pfx, dy = y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			const float G = fr_expf_inrange(power);
+			const float alpha = fminf(0.99f, o * G);
+			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);
+			if (has)
+			{
+				float m2x, m2y, qx, qy, qw, wcol, gop;
+				fr_pair_backward_t<false>(st, alpha, G, dx, dy, cx, cy, cz, o, r0, r1, r2, g0, g1, g2, bg_dot, ddelx_dx, ddely_dy,
+				                          m2x, m2y, qx, qy, qw, wcol, gop);
+				atomicAdd(&s_acc[wave][0][j], m2x); atomicAdd(&s_acc[wave][1][j], m2y);
+				atomicAdd(&s_acc[wave][2][j], qx); atomicAdd(&s_acc[wave][3][j], qy); atomicAdd(&s_acc[wave][4][j], qw);
+				atomicAdd(&s_acc[wave][5][j], wcol * g0); atomicAdd(&s_acc[wave][6][j], wcol * g1); atomicAdd(&s_acc[wave][7][j], wcol * g2);
+				atomicAdd(&s_acc[wave][8][j], gop);
+			}
+		}
+		__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
+		if (lane < m)
+		{
+			const size_t id = my_id;
+			float a;
+			if ((a = s_acc[wave][0][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id, a);
+			if ((a = s_acc[wave][1][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id + 1, a);
+			if ((a = s_acc[wave][2][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id, a);
+			if ((a = s_acc[wave][3][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 1, a);
+			if ((a = s_acc[wave][4][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 3, a);
+			if ((a = s_acc[wave][5][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id, a);
+			if ((a = s_acc[wave][6][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 1, a);
+			if ((a = s_acc[wave][7][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 2, a);
+			if ((a = s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
+		}
+	}
+}
+
+// Per Gaussian: the Jacobian chain of backward.cu:276-475,532-583 applied ONCE to the summed u (power 1 only).
+template <bool HAS_SR, bool HAS_SH>
+__global__ __launch_bounds__(FR_THREADS) void k_backward_finish(FrParams p, FrBwdArgs b, float* __restrict__ dL_dsh)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= p.P || p.radii[i] <= 0) return;
+	float vm[16], pm[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	fr_f3 po = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+	float c3[6];
+#pragma unroll
+	for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
+	const float u[5] = { b.dL_dmean2D[3 * (size_t)i], b.dL_dmean2D[3 * (size_t)i + 1], b.dL_dconic[4 * (size_t)i],
+	                     b.dL_dconic[4 * (size_t)i + 1], b.dL_dconic[4 * (size_t)i + 3] };
+	float A[3][5];
+	float B[6][3];
+	fr_mean_jacobian(po, c3, vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, B);
+	float dm[3];
+#pragma unroll
+	for (int r = 0; r < 3; r++) dm[r] = A[r][0] * u[0] + A[r][1] * u[1] + A[r][2] * u[2] + A[r][3] * u[3] + A[r][4] * u[4];
+	if constexpr (HAS_SH)
+	{
+		fr_f3 cp = { p.campos[0], p.campos[1], p.campos[2] };
+		float coef[16];
+		float Dm[3][3];
+		fr_sh_backward_jacobian(p.D, po, cp, p.shs + (size_t)p.M * i, p.clamped + 3 * (size_t)i, coef, Dm);
+		const float gc[3] = { b.dL_dcolors[3 * (size_t)i], b.dL_dcolors[3 * (size_t)i + 1], b.dL_dcolors[3 * (size_t)i + 2] };
+#pragma unroll
+		for (int r = 0; r < 3; r++) dm[r] += Dm[r][0] * gc[0] + Dm[r][1] * gc[1] + Dm[r][2] * gc[2];
+		if (p.D > 0)
+		{
+			const int nsh = (p.D + 1) * (p.D + 1);
+			for (int k = 0; k < nsh; k++)
+				for (int c = 0; c < 3; c++)
+					dL_dsh[((size_t)i * p.M + k) * 3 + c] = coef[k] * (p.clamped[3 * (size_t)i + c] ? 0.f : 1.f) * gc[c];
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < 3; r++) b.dL_dmean3D[3 * (size_t)i + r] = dm[r];
+	float dcov[6];
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+	{
+		dcov[r] = B[r][0] * u[2] + B[r][1] * u[3] + B[r][2] * u[4];
+		b.dL_dcov3D[6 * (size_t)i + r] = dcov[r];
+	}
+	if constexpr (HAS_SR)
+	{
+		fr_f3 sc = { p.scales[3 * (size_t)i], p.scales[3 * (size_t)i + 1], p.scales[3 * (size_t)i + 2] };
+		fr_f4 q = { p.rots[4 * (size_t)i], p.rots[4 * (size_t)i + 1], p.rots[4 * (size_t)i + 2], p.rots[4 * (size_t)i + 3] };
+		fr_f3 ds; fr_f4 dr;
+		fr_cov3d_backward(sc, p.mod, q, dcov, ds, dr);
+		b.dL_dscale[3 * (size_t)i] = ds.x; b.dL_dscale[3 * (size_t)i + 1] = ds.y; b.dL_dscale[3 * (size_t)i + 2] = ds.z;
+		b.dL_drot[4 * (size_t)i] = dr.x; b.dL_drot[4 * (size_t)i + 1] = dr.y; b.dL_drot[4 * (size_t)i + 2] = dr.z; b.dL_drot[4 * (size_t)i + 3] = dr.w;
 	}
 }
 
@@ -1789,6 +2073,29 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	b.dL_dmean3D = dL_dmeans3D; b.dL_dcov3D = dL_dcov3D; b.dL_dscale = dL_dscales; b.dL_drot = dL_drotations;
 	const bool sr = g->scales != nullptr, sh = g->shs != nullptr;
 	dim3 grid(p.T, 1), block(FR_THREADS);
+	b.only_flagged = nullptr;
+	b.u_only = 0;
+	if (power == 1)
+	{
+		// gradients: sum u per splat in the tile kernel, Jacobian chain once per Gaussian; tiles that do not fit the LDS
+		// index are redone (u only) by the scan kernel.  The flag array borrows tile_fill, which is dead after binning.
+		uint8_t* fallback = (uint8_t*)p.tile_fill;
+		hipLaunchKernelGGL(k_backward_lin_tile, dim3(p.T), block, 0, s, p, b, fallback);
+		if ((rc = fr_check_launch("k_backward_lin_tile"))) return rc;
+		b.only_flagged = fallback;
+		b.u_only = 1;
+		if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
+		else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
+		else if (sh) hipLaunchKernelGGL((k_backward_tile<false, true>), grid, block, 0, s, p, b);
+		else hipLaunchKernelGGL((k_backward_tile<false, false>), grid, block, 0, s, p, b);
+		if ((rc = fr_check_launch("k_backward_tile(flagged)"))) return rc;
+		dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
+		if (sr && sh) hipLaunchKernelGGL((k_backward_finish<true, true>), gp, block, 0, s, p, b, dL_dsh);
+		else if (sr) hipLaunchKernelGGL((k_backward_finish<true, false>), gp, block, 0, s, p, b, dL_dsh);
+		else if (sh) hipLaunchKernelGGL((k_backward_finish<false, true>), gp, block, 0, s, p, b, dL_dsh);
+		else hipLaunchKernelGGL((k_backward_finish<false, false>), gp, block, 0, s, p, b, dL_dsh);
+		return fr_check_launch("k_backward_finish");
+	}
 	if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
 	else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
 	else if (sh) hipLaunchKernelGGL((k_backward_tile<false, true>), grid, block, 0, s, p, b);
