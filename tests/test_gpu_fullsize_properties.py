@@ -78,3 +78,28 @@ def test_one_view_against_oracle(full, gpu, oracle):
     want_score = float((H_o.astype(np.float64) * f["H_inv"].cpu().double().numpy()).sum())
     s = f["sc"].run(f["w2c"][5:6], H_inv=f["H_inv"])["scores"].item()
     assert abs(s - want_score) <= 1e-4 * abs(want_score)
+
+
+def test_config4_train_step_against_oracle(gpu, oracle):
+    """BASELINE.json configs[3]: 2M Gaussians, 512x512, forward + power=1 backward with dL_dpix = N(0,1) seed 44 --
+    the whole thing against the oracle (about a minute of CPU)."""
+    from fisher_rast import synthetic
+    from gpu_util import hip_forward, hip_backward, assert_close
+    P, W, H = 2_000_000, 512, 512
+    act = {k: v.numpy() for k, v in synthetic.activate(synthetic.room_shell(P, seed=4)).items()}
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(1, seed=4))[0].numpy()
+    tp = oracle.transform_points(w2c, act["means3D"])
+    cam = oracle.setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4))
+    kw = dict(colors_precomp=act["rgb_colors"], scales=act["scales"], rotations=act["rotations"])
+    want = oracle.rasterize_forward(cam, tp, act["opacities"], **kw)
+    got = hip_forward(gpu, cam, tp, act["opacities"], **kw)
+    assert got["num_rendered"] == want["num_rendered"] > 1_000_000
+    assert np.array_equal(got["radii"], want["radii"]) and np.array_equal(got["ranges"], want["ranges"])
+    assert np.array_equal(got["point_list"], want["point_list"])
+    assert np.array_equal(got["n_contrib"], want["n_contrib"])
+    assert np.array_equal(np.ascontiguousarray(got["color"]).view(np.uint32), want["color"].view(np.uint32))
+    dL = torch.randn((3, H, W), generator=torch.Generator().manual_seed(44)).numpy()
+    gw = oracle.rasterize_backward(cam, want, dL, 1)
+    gg = hip_backward(gpu, cam, got, dL, 1)
+    for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
+        assert_close(gg[n], gw[n], 1e-4, n, atol_frac=2e-5)
