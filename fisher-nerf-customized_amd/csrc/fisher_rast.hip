@@ -104,6 +104,11 @@ __device__ __forceinline__ int wave_max_i(int v)
 	return v;
 }
 
+// Hardware exponential (v_exp_f32 after one multiply, ~1 ulp of 2^x) for the SCORER only: its bar is 1e-4 on the scores, and a
+// pair whose alpha sits within an ulp of 1/255 (or a pixel whose T sits within an ulp of 1e-4) carries a weight far below
+// that.  The single-view rasteriser keeps fr_expf, whose forward outputs are bit-identical to the oracle's.
+__device__ __forceinline__ float fr_exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 // conservative lower bound on `power` below which alpha = opacity*exp(power) is certainly < 1/255
 __device__ __forceinline__ float fr_power_threshold(float opacity)
 {
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const bool pass = !done && !(power > 0.0f) && !(power < thr);
 			if (__any(pass))
 			{
-				const float G = fr_expf_inrange(power);
+				const float G = fr_exp_hw(power);
 				const float alpha = fminf(0.99f, o * G);
 				const bool ok = pass && !(alpha < 1.0f / 255.0f);
 				const float test_T = T * (1 - alpha);
@@ -1259,7 +1264,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			for (int q = 0; q < NB; q++) r[q] = fr_bperm_f(b[q], j);
 			const float dx = x - pfx, dy = y - pfy;
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-			const float G = fr_expf_inrange(power);
+			const float G = fr_exp_hw(power);
 			const float alpha = fminf(0.99f, o * G);
 			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);   // exact tests
 			FR_STAT(dbg_hits += (int)__popcll(__ballot(has));)
