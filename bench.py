@@ -184,6 +184,9 @@ def main():
         }
         if world == 1 and a.cpu_views > 0:
             out["cpu_baseline"] = cpu_baseline(P, W, H, seed, a.cpu_views, C)
+            # the reference's CPU occupancy / frontier step (planning/astar.py), timed on the same host cores
+            from oracle import occupancy_frontier
+            out["cpu_occupancy_frontier"] = occupancy_frontier.time_baseline(n_frames=4, W=W, H=H, seed=seed)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
