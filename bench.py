@@ -133,10 +133,12 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    buf = (ctypes.c_float * max(a.steps, 1))()
-    n_ev = lib.fr_profile_fetch(buf, a.steps)
+    buf = (ctypes.c_float * max(a.steps * 16, 1))()
+    n_ev = lib.fr_profile_fetch(buf, a.steps * 16)
     lib.fr_profile_enable(0)
     assert int(last["status"].cpu()[1]) == 0, "tile-instance buffer overflowed inside the timed region"
+    # a step launches the dominant kernel once per view group (FisherScorer.n_streams groups on separate streams)
+    launches_per_step = max(1, n_ev // max(a.steps, 1))
     kern_ms = float(np.mean([buf[i] for i in range(n_ev)])) if n_ev > 0 else float("nan")
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -151,7 +153,7 @@ def main():
         # algorithmic bytes of ONE k_fisher_tile_v2 launch: per tile instance pass 1 reads the key (8)
         # and the 32-byte splat record; pass 2 reads those again plus the packed static record (mean, cov3D, rgb, H_inv:
         # 64 B at C = 4, 128 B at C = 11); plus one partial score per (view, tile).
-        kern_bytes = R * ((8 + 32) + (8 + 32) + (64 if C == 4 else 128)) + 4.0 * V * T
+        kern_bytes = (R * ((8 + 32) + (8 + 32) + (64 if C == 4 else 128)) + 4.0 * V * T) / launches_per_step
         ach = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
         # whole-path algorithmic bytes per view, SURVEY.md 8(d)
         B_view = (12 * P + 44 * vis_count.mean() + 24 * num_rendered.mean() + 40 * num_rendered.mean() +
@@ -161,7 +163,7 @@ def main():
         if os.path.exists(pmc_file):
             try:
                 pm = json.load(open(pmc_file))
-                if pm.get("gaussians") == P and pm.get("views") == V and pm.get("size") == W and pm.get("columns") == C:
+                if pm.get("gaussians") == P and pm.get("views") == V // launches_per_step and pm.get("size") == W and pm.get("columns") == C:
                     traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -177,8 +179,8 @@ def main():
             "fisher_scores_per_s": views_per_s * P * C,
             "roofline": {"bound": "hbm", "kernel": "k_fisher_tile_v2", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
-                         "kernel_share_of_step": (kern_ms / (1e3 * dt / a.steps)) if kern_ms == kern_ms else None},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes, "launches_per_step": launches_per_step,
+                         "views_per_launch": V // launches_per_step},
             "path": {"bytes_per_view": float(B_view), "achieved_GBps": float(B_view * views_per_s / world / 1e9),
                      "frac_of_hbm_peak": float(B_view * views_per_s / world / 1e9 / HBM_PEAK_GBS)},
         }

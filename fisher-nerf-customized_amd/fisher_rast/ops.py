@@ -9,6 +9,7 @@ Three groups of entry points:
   * `knn_dist2` -- simple_knn._C.distCUDA2.
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -208,8 +209,11 @@ class FisherScorer:
         self.view = _prep(raster_settings.viewmatrix, d)
         self.proj = _prep(raster_settings.projmatrix, d)
         self.campos = _prep(raster_settings.campos, d)
-        self._ws = None
-        self._ws_key = None
+        self._ws = {}
+        self._side_streams = []
+        # measured on MI355X (500k Gaussians, 64 views): 2 groups on 2 streams 7.6 ms per step against 6.5 ms for one launch --
+        # the half-size launches lose more than the overlap gains, so one group is the default
+        self.n_streams = max(1, int(os.environ.get("FR_STREAMS", "1")))
         self.per_view_capacity = max(int(0.75 * self.P), 1 << 16)
         self.cfg = _raster_cfg(self.P, self.H, self.W, raster_settings.tanfovx, raster_settings.tanfovy,
                                raster_settings.scale_modifier, raster_settings.sh_degree, 0,
@@ -221,55 +225,78 @@ class FisherScorer:
         per_view = max(self.P, 1) * 36 + self.per_view_capacity * 8
         return max(1, int(self.WORKSPACE_BUDGET // per_view))
 
-    def _workspace(self, V, max_rendered):
-        key = (V, max_rendered)
-        if self._ws is None or self._ws_key != key:
-            nbytes = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, V, max_rendered, self.columns))
-            if nbytes == 0:
-                raise FisherRastError("fr_fisher_workspace_bytes: bad argument")
-            if self._ws is None or self._ws.numel() < nbytes:
-                self._ws = None
-                self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
-            self._ws_key = key
-        return self._ws
+    def _workspace(self, V, max_rendered, slot=0):
+        nbytes = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, V, max_rendered, self.columns))
+        if nbytes == 0:
+            raise FisherRastError("fr_fisher_workspace_bytes: bad argument")
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < nbytes:
+            self._ws[slot] = None
+            ws = self._ws[slot] = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        return ws
 
     def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False):
         """Enqueue one batch (no sync).  w2c: [V,4,4] world->camera on the device.
-        Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4]."""
+        Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4].
+
+        The batch is cut into `self.n_streams` groups of views that run on separate HIP streams with separate
+        workspaces: the binning kernels of one group (latency-bound, few waves) overlap the tile kernel of the other
+        (VALU-bound).  Groups are whole multiples of 8 views so that the XCD-aware tile mapping stays exact."""
         d = self.dev
         w2c = _prep(w2c.reshape(-1, 4, 4), d)
         V = int(w2c.shape[0])
         C = self.columns
-        max_rendered = V * self.per_view_capacity
-        ws = self._workspace(V, max_rendered)
-        fc = FisherCfg()
-        fc.n_views, fc.columns, fc.dL_dpix = V, C, self.dL
-        fc.w2c = _ptr(w2c)
+        PC = self.P * C
         scores = None
         if H_inv is not None:
             H_inv = _prep(H_inv, d)
-            want = (V * self.P * C) if H_inv_per_view else (self.P * C)
+            want = (V * PC) if H_inv_per_view else PC
             if H_inv.numel() != want:
                 raise ValueError(f"H_inv has {H_inv.numel()} elements, expected {want}")
-            fc.H_inv = _ptr(H_inv)
-            fc.H_inv_view_stride = self.P * C if H_inv_per_view else 0
             scores = torch.zeros((V,), dtype=torch.float32, device=d)
-            fc.out_scores = _ptr(scores)
         if out_H is not None:
-            want = (V * self.P * C) if out_H_per_view else (self.P * C)
+            want = (V * PC) if out_H_per_view else PC
             if out_H.numel() != want or out_H.dtype != torch.float32 or not out_H.is_contiguous() or out_H.device != d:
                 raise ValueError("out_H must be a contiguous fp32 device tensor of [V,]P*columns elements")
-            fc.out_H = _ptr(out_H)
-            fc.out_H_view_stride = self.P * C if out_H_per_view else 0
         vis = torch.zeros((V,), dtype=torch.int32, device=d)
         nr = torch.zeros((V,), dtype=torch.int32, device=d)
-        status = torch.zeros((4,), dtype=torch.int32, device=d)
-        fc.out_vis_count = vis.data_ptr()
-        fc.out_num_rendered = nr.data_ptr()
+        n_groups = self.n_streams if (V >= 16 * self.n_streams and V % (8 * self.n_streams) == 0) else 1
+        status = torch.zeros((n_groups, 4), dtype=torch.int32, device=d)
+        per = V // n_groups
+        cur = torch.cuda.current_stream(d)
+        if n_groups > 1 and len(self._side_streams) < n_groups - 1:
+            self._side_streams = [torch.cuda.Stream(device=d) for _ in range(n_groups - 1)]
         with torch.cuda.device(d):
-            _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
-                                                ws.data_ptr(), ws.numel(), max_rendered, status.data_ptr(),
-                                                _stream(d)), "fr_fisher_views")
+            for gi in range(n_groups):
+                v0, v1 = gi * per, (gi + 1) * per
+                stream = cur if gi == 0 else self._side_streams[gi - 1]
+                if gi > 0:
+                    stream.wait_stream(cur)
+                Vg = v1 - v0
+                max_rendered = Vg * self.per_view_capacity
+                ws = self._workspace(Vg, max_rendered, gi)
+                fc = FisherCfg()
+                fc.n_views, fc.columns, fc.dL_dpix = Vg, C, self.dL
+                fc.w2c = ctypes.c_void_p(w2c.data_ptr() + v0 * 64)
+                if H_inv is not None:
+                    fc.H_inv = ctypes.c_void_p(H_inv.data_ptr() + (v0 * PC * 4 if H_inv_per_view else 0))
+                    fc.H_inv_view_stride = PC if H_inv_per_view else 0
+                    fc.out_scores = ctypes.c_void_p(scores.data_ptr() + v0 * 4)
+                if out_H is not None:
+                    fc.out_H = ctypes.c_void_p(out_H.data_ptr() + (v0 * PC * 4 if out_H_per_view else 0))
+                    fc.out_H_view_stride = PC if out_H_per_view else 0
+                fc.out_vis_count = vis.data_ptr() + v0 * 4
+                fc.out_num_rendered = nr.data_ptr() + v0 * 4
+                _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
+                                                    ws.data_ptr(), ws.numel(), max_rendered,
+                                                    status.data_ptr() + gi * 16, ctypes.c_void_p(stream.cuda_stream)),
+                           "fr_fisher_views")
+            for gi in range(1, n_groups):
+                cur.wait_stream(self._side_streams[gi - 1])
+        if n_groups > 1:
+            status = torch.stack([status[:, 0].sum(), status[:, 1].max(), status[:, 2].max(), status[:, 3].max()]).to(torch.int32)
+        else:
+            status = status[0]
         return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv))
 
     def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False):
