@@ -1268,11 +1268,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const float alpha = fminf(0.99f, o * G);
 			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);   // exact tests
 			FR_STAT(dbg_hits += (int)__popcll(__ballot(has));)
-			if (has)
+			// Predicated, not branched: every lane runs the arithmetic on a scratch copy of its recurrences and commits with
+			// selects -- cheaper than the exec-mask juggling and register copies a divergent region costs here.
 			{
+				FrPixState ns = st;
 				float m2x, m2y, qx, qy, qw, wcol, gop;
-				fr_pair_backward_t<true>(st, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
+				fr_pair_backward_t<true>(ns, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
 				                         m2x, m2y, qx, qy, qw, wcol, gop);
+				st.T = has ? ns.T : st.T;
+				st.accum0 = has ? ns.accum0 : st.accum0; st.accum1 = has ? ns.accum1 : st.accum1; st.accum2 = has ? ns.accum2 : st.accum2;
+				st.lastc0 = has ? ns.lastc0 : st.lastc0; st.lastc1 = has ? ns.lastc1 : st.lastc1; st.lastc2 = has ? ns.lastc2 : st.lastc2;
+				st.last_alpha = has ? ns.last_alpha : st.last_alpha;
 				float leaf2[C];
 #pragma unroll
 				for (int q = 0; q < 3; q++)
@@ -1293,13 +1299,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 				}
 				if constexpr (HAS_HINV)
 				{
+					float add = 0.f;
 #pragma unroll
-					for (int c = 0; c < C; c++) score += leaf2[c] * r[HO + c];
+					for (int c = 0; c < C; c++) add += leaf2[c] * r[HO + c];
+					score += has ? add : 0.f;
 				}
 				if constexpr (HAS_OUTH)
 				{
+					if (has)
+					{
 #pragma unroll
-					for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], leaf2[c]);
+						for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], leaf2[c]);
+					}
 				}
 			}
 		}
