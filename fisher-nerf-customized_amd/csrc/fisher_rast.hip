@@ -85,6 +85,7 @@ struct FrParams {
 	uint8_t* clamped;            // [V][P][3]
 	uint32_t* tile_cnt; uint32_t* tile_off; uint32_t* tile_fill; // [V][T]
 	uint64_t* keys; long long key_capacity;
+	uint32_t* blk_base;          // [V][gridDim.x][T] or null: start of each preprocess workgroup's range inside a tile segment
 	uint32_t* big_list;          // [0] = number of tiles with more than FR_SORT_SMALL_KEYS splats, [16..] their (view*T + tile)
 	int* status;                 // [4]
 	int* vis_count;              // [V] or null
@@ -236,7 +237,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 		for (int t = tid; t < p.T; t += FR_THREADS)
 		{
 			uint32_t c = hist[t];
-			if (c) atomicAdd(&cnt[t], c);
+			if (c)
+			{
+				// the returned running count is this workgroup's private range inside the tile's segment: k_scatter_keys,
+				// launched with the same decomposition, hands out slots inside it without counting again
+				const uint32_t before = atomicAdd(&cnt[t], c);
+				if (p.blk_base) p.blk_base[((size_t)v * gridDim.x + blockIdx.x) * p.T + t] = before;
+			}
 		}
 	}
 	if (p.vis_count)
@@ -339,7 +346,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 	const uint32_t* off = p.tile_off + (size_t)v * p.T;
 	uint32_t* fill = p.tile_fill + (size_t)v * p.T;
 	const bool lds = p.T <= FR_MAX_LDS_TILES;
-	if (lds)
+	if (lds && p.blk_base)
+	{
+		const uint32_t* bb = p.blk_base + ((size_t)v * gridDim.x + blockIdx.x) * p.T;
+		for (int t = tid; t < p.T; t += FR_THREADS) { s_cnt[t] = 0; s_base[t] = off[t] + bb[t]; }   // bb[t] is only read where this workgroup counted > 0
+		__syncthreads();
+	}
+	else if (lds)
 	{
 		for (int t = tid; t < p.T; t += FR_THREADS) s_cnt[t] = 0;
 		__syncthreads();
@@ -1861,6 +1874,19 @@ __global__ __launch_bounds__(FR_THREADS) void k_finish_sh(FrParams p, const floa
 // =========================================================================================================
 static inline size_t fr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Gaussians per thread of k_preprocess / k_scatter_keys: enough per workgroup for the LDS tile histograms to aggregate,
+// enough workgroups to fill 256 CUs.
+static inline int fr_pick_G(long long P, long long V)
+{
+	long long gwant = (P * V) / ((long long)FR_THREADS * 2048);
+	return (int)(gwant < 1 ? 1 : (gwant > FR_G_MAX ? FR_G_MAX : gwant));
+}
+static inline long long fr_preprocess_blocks(long long P, long long V)
+{
+	const long long per_block = (long long)FR_THREADS * fr_pick_G(P, V);
+	return (P + per_block - 1) / per_block;
+}
+
 struct FrLayout {
 	// geometry
 	size_t splat, cov3D, rgb, clamped, geom_bytes;
@@ -1976,9 +2002,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 		if ((rc = fr_check_launch("k_cov3d"))) return rc;
 		p.cov3D = p.cov3D_out;
 	}
-	// enough Gaussians per workgroup for the LDS tile histograms to aggregate, enough workgroups to fill 256 CUs
-	long long gwant = ((long long)P * p.V) / ((long long)FR_THREADS * 2048);
-	p.G = (int)(gwant < 1 ? 1 : (gwant > FR_G_MAX ? FR_G_MAX : gwant));
+	p.G = fr_pick_G(P, p.V);
 	const int per_block = FR_THREADS * p.G;
 	dim3 gridP((P + per_block - 1) / per_block, p.V);
 	const size_t hist_lds = p.T <= FR_MAX_LDS_TILES ? (size_t)p.T * 4 : 16;
@@ -2127,7 +2151,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 
 // ---- fused Fisher scorer ---------------------------------------------------------------------------------
 struct FrFisherLayout {
-	size_t radii, splat, packed, big_list, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, splat, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
@@ -2139,6 +2163,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
+	L.blk_base = o; o = fr_align(o + (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4);
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.tile_off = o; o = fr_align(o + (size_t)(V * T) * 4);
@@ -2226,6 +2251,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	p.tile_fill = (uint32_t*)(ws + L.tile_fill);
 	p.status = (int*)(ws + L.status);
 	p.big_list = (uint32_t*)(ws + L.big_list);
+	p.blk_base = (uint32_t*)(ws + L.blk_base);
 	p.keys = (uint64_t*)(ws + L.keys);
 	p.key_capacity = max_rendered;
 	p.vis_count = fc->out_vis_count;
