@@ -214,3 +214,86 @@ def test_popgs_diag_estimator(config1, gpu, oracle):
     assert torch.isfinite(t) and torch.isfinite(d) and float(d) >= 0.0 and float(t) < 0.0
     scores, c2ws = slam.pose_eval_popgs([p.to(gpu) for p in c["c2w"][:2]], criterion="dopt", K=1)
     assert scores.shape == (2,) and c2ws.shape == (2, 4, 4)
+
+
+def _crowded_scene(P, seed):
+    """P tiny, faint splats that all project into the 16x16 tile at the image centre of a 48x48 view."""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(2.0, 6.0, P).astype(np.float32)
+    # pixel = 24 * x / z + 23.5 ; tile (1,1) spans pixels 16..31
+    u = rng.uniform(16.5, 30.5, P); v = rng.uniform(16.5, 30.5, P)
+    means = np.stack([(u - 23.5) / 24.0 * z, (v - 23.5) / 24.0 * z, z], 1).astype(np.float32)
+    scales = np.full((P, 3), 0.004, np.float32) * z[:, None]
+    rot = np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1))
+    op = rng.uniform(0.005, 0.012, P).astype(np.float32)
+    col = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    return means, col, rot, op, scales
+
+
+@pytest.mark.parametrize("P,expect", [(70_000, "tile_over_65535"), (30_000, "strip_list_over_3840")])
+@pytest.mark.parametrize("columns", [4, 11])
+def test_fallback_paths_for_crowded_tiles(gpu, oracle, P, expect, columns):
+    """Tiles whose lists do not fit k_fisher_tile_v2's LDS index (more than 65535 splats in a tile, or more than 3840
+    contributing splats per 16x4 strip) are flagged and redone by the scan kernel: same results."""
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    from fisher_rast import synthetic
+    W = H = 48
+    K = synthetic.intrinsics(W, H)
+    means, col, rot, op, sc = _crowded_scene(P, 3)
+    cam = setup_camera(W, H, K, np.eye(4), device=gpu)
+    ocam = oracle.setup_camera(W, H, K, np.eye(4))
+    w2c = np.eye(4, dtype=np.float32)[None]
+    H_o, vis, fwd, g = oracle.compute_hessian(ocam, w2c[0], means, col, rot, op, sc, columns=columns, return_all=True)
+    counts = fwd["ranges"][:, 1] - fwd["ranges"][:, 0]
+    if expect == "tile_over_65535":
+        assert counts.max() > 65535
+    else:
+        assert 3840 * 4 < counts.max() <= 65535 and fwd["n_contrib"].max() > 300
+    t = [torch.from_numpy(a).to(gpu) for a in (means, col, rot, op, sc)]
+    scorer = FisherScorer(cam, *t, columns=columns)
+    cur = torch.zeros((P, columns), device=gpu)
+    r = scorer.run(torch.from_numpy(w2c).to(gpu), out_H=cur)
+    assert int(r["vis_count"][0]) == vis and int(r["num_rendered"][0]) == fwd["num_rendered"]
+    assert_close(cur.cpu().numpy(), H_o, 1e-4, "cur_H", atol_frac=1e-7)
+    Hi = torch.rand((P, columns), generator=torch.Generator().manual_seed(1)).to(gpu)
+    s = scorer.run(torch.from_numpy(w2c).to(gpu), H_inv=Hi)["scores"].cpu().numpy()
+    want = float((H_o.astype(np.float64) * Hi.cpu().double().numpy()).sum())
+    assert abs(s[0] - want) <= 1e-4 * abs(want)
+    # the single-view gradient path has the same fallback (k_backward_lin_tile -> k_backward_tile, u only)
+    from gpu_util import hip_forward, hip_backward
+    got = hip_forward(gpu, ocam, means, op, colors_precomp=col, scales=sc, rotations=rot)
+    assert np.array_equal(got["point_list"], fwd["point_list"])
+    dL = np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32)
+    gw = oracle.rasterize_backward(ocam, fwd, dL, 1)
+    gg = hip_backward(gpu, ocam, got, dL, 1)
+    for n in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcolors"):
+        assert_close(gg[n], gw[n], 1e-4, n, atol_frac=2e-5)
+
+
+def test_more_tiles_than_the_lds_histogram_holds(gpu, oracle):
+    """T = 65 x 65 = 4225 tiles > FR_MAX_LDS_TILES: binning falls back to global counters."""
+    from fisher_rast import synthetic
+    from gpu_util import hip_forward
+    W = H = 1040
+    P = 3000
+    act = {k: v.numpy() for k, v in synthetic.activate(synthetic.room_shell(P, seed=8)).items()}
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(1, seed=8))[0].numpy()
+    tp = oracle.transform_points(w2c, act["means3D"])
+    cam = oracle.setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4))
+    kw = dict(colors_precomp=act["rgb_colors"], scales=act["scales"], rotations=act["rotations"])
+    want = oracle.rasterize_forward(cam, tp, act["opacities"], **kw)
+    got = hip_forward(gpu, cam, tp, act["opacities"], **kw)
+    assert got["num_rendered"] == want["num_rendered"] and np.array_equal(got["ranges"], want["ranges"])
+    assert np.array_equal(got["point_list"], want["point_list"])
+    assert np.array_equal(np.ascontiguousarray(got["color"]).view(np.uint32), want["color"].view(np.uint32))
+    # and the batched scorer on the same image size
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    gcam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    t = {k: torch.from_numpy(v).to(gpu) for k, v in act.items()}
+    sc = FisherScorer(gcam, t["means3D"], t["rgb_colors"], t["rotations"], t["opacities"], t["scales"])
+    cur = torch.zeros((P, 4), device=gpu)
+    sc.run(torch.from_numpy(w2c[None]).to(gpu), out_H=cur)
+    H_o, _ = oracle.compute_hessian(cam, w2c, act["means3D"], act["rgb_colors"], act["rotations"], act["opacities"], act["scales"])
+    assert_close(cur.cpu().numpy(), H_o, 1e-4, "cur_H", atol_frac=1e-7)
