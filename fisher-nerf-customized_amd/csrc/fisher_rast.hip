@@ -1014,6 +1014,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 	for (int k = 0; k < PS / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
 }
 
+#define FR_E255 (-7.994353436858858f)     // log2(1/255)
+// exponent of the scorer's alpha (see k_fisher_tile_v2): e = power*log2(e) + log2(opacity)
+__device__ __forceinline__ float fr_scorer_exponent(float hcx, float ncy, float hcz, float dx, float dy, float lo, float& power)
+{
+	const float t = __builtin_fmaf(hcx, dx, ncy * dy);
+	const float v = hcz * dy;
+	power = __builtin_fmaf(dx, t, v * dy);
+	return __builtin_fmaf(power, 1.44269504088896341f, lo);
+}
+// wave votes on the scalar unit (the __any / __all builtins go through a VGPR round trip)
+__device__ __forceinline__ bool fr_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+__device__ __forceinline__ bool fr_all(bool x) { return __builtin_amdgcn_ballot_w64(!x) == 0ull; }
 __device__ __forceinline__ float fr_readlane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_float(__builtin_amdgcn_ds_bpermute(l << 2, __float_as_int(x))); }
 
@@ -1027,8 +1039,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 {
 	__shared__ float s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];
 	constexpr int PS = FrPackSize<C>::value;
-	constexpr int NB = ((C == 11) ? 39 : 18) + (HAS_HINV ? C : 0);   // per-entry registers of pass 2: rgb[3], A[15], (Cm[21]), [H_inv[C]]
-	constexpr int HO = (C == 11) ? 39 : 18;       // offset of H_inv inside them
+	// per-entry registers of pass 2: rgb[3], A'[15], (Cm'[21]), k3, [H_inv columns]
+	constexpr int KO = (C == 11) ? 39 : 18;       // offset of k3 = 1/opacity^2 (times H_inv[3] when only the score is wanted)
+	constexpr int HO = KO + 1;                    // offset of the H_inv columns
+	constexpr bool FOLD3 = HAS_HINV && !HAS_OUTH; // H_inv[3] folded into k3
+	constexpr int NB = HO + (HAS_HINV ? C : 0);
 	__shared__ uint16_t s_wl[4][FR_WCAP];
 	__shared__ float s_red[4];
 	__shared__ int s_ovf;
@@ -1060,12 +1075,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	// already in flight), keeps the ones whose conservative alpha footprint meets its 16x4 strip (one ballot), and walks
 	// the set bits in order, broadcasting a record from its owning lane with v_readlane.  No LDS staging, no workgroup
 	// barrier: a wave whose 64 pixels are all finished simply leaves.
-	bool done = !inside;
+	// The scorer's alpha: a = 2^e, e = power*log2(e) + log2(opacity), power = dx*(hcx*dx + ncy*dy) + (hcz*dy)*dy with
+	// (hcx, ncy, hcz) = (-conic.x/2, -conic.y, -conic.z/2): the same value as forward.cu:338-346 up to rounding, evaluated by
+	// the identical instruction sequence in both passes (fr_scorer_exponent), so the two passes agree on every pair.
+	// The wave votes are kept as 64-bit scalar masks (v_cmp writes them, s_and/s_or combine them).
+	unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
 	float T = 1.0f;
 	int last = 0;
 	int wcnt = 0;                                  // wave-uniform
 #ifdef FR_LOOPSTATS
-	int dbg_p1 = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0;   // -DFR_LOOPSTATS + FR_DEBUG_MODE >= 2: loop-trip counters
+	int dbg_p1 = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_p1any = 0, dbg_p1con = 0;   // -DFR_LOOPSTATS + FR_DEBUG_MODE >= 2: loop-trip counters
 #define FR_STAT(x) x
 #else
 #define FR_STAT(x)
@@ -1090,7 +1109,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
 		const bool ov = (base + lane < n) && hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi)
 		                && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
-		const float thr_l = fr_power_threshold(q1.y);
+		const float hcx_l = -0.5f * q0.z, ncy_l = -q0.w, hcz_l = -0.5f * q1.x;
+		const float lo_l = __builtin_amdgcn_logf(q1.y);          // v_log_f32: log2(opacity); opacity <= 1/255 never gets here (hx < 0)
 		unsigned long long todo = __ballot(ov);
 		while (todo)
 		{
@@ -1098,32 +1118,35 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			todo &= todo - 1ull;
 			FR_STAT(dbg_p1++;)
 			const float x = fr_readlane_f(q0.x, j), y = fr_readlane_f(q0.y, j);
-			const float cx = fr_readlane_f(q0.z, j), cy = fr_readlane_f(q0.w, j), cz = fr_readlane_f(q1.x, j);
-			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(thr_l, j);
-			// forward.cu:338-357, predicated: same comparisons (written negated so that NaN behaves as in the reference)
+			const float hcx = fr_readlane_f(hcx_l, j), ncy = fr_readlane_f(ncy_l, j), hcz = fr_readlane_f(hcz_l, j);
+			const float lo = fr_readlane_f(lo_l, j);
 			const float dx = x - pfx, dy = y - pfy;
-			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-			const bool pass = !done && !(power > 0.0f) && !(power < thr);
-			if (__any(pass))
+			float power;
+			const float e = fr_scorer_exponent(hcx, ncy, hcz, dx, dy, lo, power);
+			// forward.cu:347-357 (power > 0 -> skip, alpha < 1/255 -> skip); NaN falls through as it does there
+			const unsigned long long skip_m = __builtin_amdgcn_fcmpf(power, 0.0f, 2 /* ogt */) | __builtin_amdgcn_fcmpf(e, FR_E255, 4 /* olt */);
+			const unsigned long long pass_m = ~(skip_m | done_m);
+			if (pass_m)
 			{
-				const float G = fr_exp_hw(power);
-				const float alpha = fminf(0.99f, o * G);
-				const bool ok = pass && !(alpha < 1.0f / 255.0f);
+				FR_STAT(dbg_p1any++;)
+				const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
 				const float test_T = T * (1 - alpha);
-				const bool kill = ok && (test_T < 0.0001f);
-				const bool contrib = ok && !kill;
-				done = done || kill;
-				T = contrib ? test_T : T;
-				last = contrib ? ((int)base + j + 1) : last;
-				if (__any(contrib))
+				const unsigned long long kill_m = pass_m & __builtin_amdgcn_fcmpf(test_T, 0.0001f, 4 /* olt */);
+				const unsigned long long contrib_m = pass_m & ~kill_m;
+				done_m |= kill_m;
+				if (contrib_m)
 				{
+					FR_STAT(dbg_p1con++;)
+					const bool contrib = __builtin_amdgcn_inverse_ballot_w64(contrib_m);
+					T = contrib ? test_T : T;
+					last = contrib ? (wcnt + 1) : last;      // 1 + index in THIS wave's list of the pixel's last contributor
 					// every lane stores the same value to the same address: no exec-mask juggling for a one-lane write
 					if (wcnt < FR_WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
 					wcnt = __builtin_amdgcn_readfirstlane(wcnt + 1);
 				}
 			}
 		}
-		if (__all(done)) break;
+		if (done_m == ~0ull) break;
 	}
 	if (lane == 0 && wcnt > FR_WCAP) s_ovf = 1;
 	__syncthreads();
@@ -1168,7 +1191,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 		FR_STAT(dbg_chunks++;)
 		// lane l owns list entry hi-1-l (descending position => bit order == back-to-front order)
 		int kk = -1;                  // unused lanes sort behind every real position (positions are descending in the lane index)
-		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY, ahx = -1.f, ahy = -1.f;
+		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, alo = 0.f, athr = INFINITY, ahx = -1.f, ahy = -1.f;
 		float b[NB];
 #pragma unroll
 		for (int q = 0; q < NB; q++) b[q] = 0.f;
@@ -1184,7 +1207,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			const uint32_t id = (uint32_t)gk[kk];
 			my_id = id;
 			const float4 a0 = splat[2 * (size_t)id], a1 = splat[2 * (size_t)id + 1];
-			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; ao = a1.y; athr = fr_power_threshold(a1.y);
+			ax = a0.x; ay = a0.y; acx = a0.z; acy = a0.w; acz = a1.x; athr = fr_power_threshold(a1.y);
+			alo = __builtin_amdgcn_logf(a1.y);
+			const float inv_o = __builtin_amdgcn_rcpf(a1.y);
 			{
 				const uint32_t eb = __float_as_uint(a1.w);
 				ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
@@ -1200,10 +1225,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			float A[3][5];
 			float B[6][3];
 			fr_mean_jacobian(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
+			// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
+			// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
 #pragma unroll
 			for (int r = 0; r < 3; r++)
+			{
+				b[3 + r * 5 + 0] = A[r][0] * ddelx_dx; b[3 + r * 5 + 1] = A[r][1] * ddely_dy;
 #pragma unroll
-				for (int c = 0; c < 5; c++) b[3 + r * 5 + c] = A[r][c];
+				for (int c = 2; c < 5; c++) b[3 + r * 5 + c] = -0.5f * A[r][c];
+			}
 			int go = 12;
 			if constexpr (C == 11)
 			{
@@ -1214,7 +1244,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 #pragma unroll
 				for (int r = 0; r < 7; r++)
 #pragma unroll
-					for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cm[r][c];
+					for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = -0.5f * Cm[r][c];
 				go = 19;
 			}
 			if constexpr (HAS_HINV)
@@ -1232,7 +1262,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 				}
 			}
 			(void)go;
+			b[KO] = inv_o * inv_o;                       // dL_dopacity = G dL_dalpha = w / opacity
+			if constexpr (FOLD3) b[KO] *= b[HO + 3];
 		}
+		const float ahcx = -0.5f * acx, ancy = -acy, ahcz = -0.5f * acz;
 		// Candidate mask.  Entry-major first: the lane that owns entry e marks the pixels of this wave's 16x4 strip that
 		// lie inside the entry's conservative alpha footprint (bit = 16*row + column = the pixel's lane).  A 64x64 bit
 		// transpose then hands every pixel-lane the set of entries that may touch it -- ~120 instructions per chunk
@@ -1270,82 +1303,85 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 			}
 		}
 		unsigned long long mask = fr_wave_transpose64(emask, lane);
-		// Chunk positions are descending, so the entries at or behind this pixel's last contributor are the FIRST t bits:
-		// t = #{ j : k_j >= last } by a 6-step binary search over the chunk (ds_bpermute), then cleared at once.
+		// Lane l owns list index hi-1-l; the pixel's contributors are the list indices below `last`, so the entries at or
+		// behind its last contributor are the FIRST hi-last bits.
 		{
-			int t = 0;
-#pragma unroll
-			for (int step = 32; step >= 1; step >>= 1)
-			{
-				const int probe = t + step - 1;                       // 0-based index of the element that would be included
-				const int kp = __builtin_amdgcn_ds_bpermute((probe & 63) << 2, kk);
-				if (probe < 64 && kp >= last) t += step;
-			}
-			mask = (t >= 64) ? 0ull : (mask & ~((1ull << t) - 1ull));
+			const int t = hi - last;
+			mask = (t >= 64) ? 0ull : (t > 0) ? (mask & ~((1ull << t) - 1ull)) : mask;
 			if (!inside) mask = 0ull;
 		}
 		// every lane walks its own set bits; the loop is wave-uniform so that all lanes take part in the bpermutes
-		while (__any(mask != 0ull))
+		while (fr_any(mask != 0ull))
 		{
 			bool has = mask != 0ull;
 			FR_STAT(dbg_steps++;)
 			const int j = has ? (__ffsll((long long)mask) - 1) : 0;
 			mask &= mask - 1ull;
-			const int kj = __builtin_amdgcn_ds_bpermute(j << 2, kk);
 			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
-			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
-			const float o = fr_bperm_f(ao, j), thr = fr_bperm_f(athr, j);
+			const float hcx = fr_bperm_f(ahcx, j), ncy = fr_bperm_f(ancy, j), hcz = fr_bperm_f(ahcz, j), lo = fr_bperm_f(alo, j);
 			float r[NB];
 #pragma unroll
-			for (int q = 0; q < NB; q++) r[q] = fr_bperm_f(b[q], j);
+			for (int q = 0; q < NB; q++)
+				if (!(FOLD3 && q == HO + 3)) r[q] = fr_bperm_f(b[q], j);
 			const float dx = x - pfx, dy = y - pfy;
-			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-			const float G = fr_exp_hw(power);
-			const float alpha = fminf(0.99f, o * G);
-			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);   // exact tests
+			float power;
+			const float e = fr_scorer_exponent(hcx, ncy, hcz, dx, dy, lo, power);     // bit-identical to pass 1's
+			has = has && !(power > 0.0f) && !(e < FR_E255);
 			FR_STAT(dbg_hits += (int)__popcll(__ballot(has));)
-			// Predicated, not branched: every lane runs the arithmetic on a scratch copy of its recurrences and commits with
-			// selects -- cheaper than the exec-mask juggling and register copies a divergent region costs here.
+			const float a_un = __builtin_amdgcn_exp2f(e);                              // opacity * G
+			// A lane without a contributor at this step runs the recurrences with alpha = 0, which leaves them unchanged
+			// (T / 1, and the colour recurrence folds a zero-alpha layer away exactly): one select instead of nine.
+			const float alpha = has ? fminf(0.99f, a_un) : 0.f;
 			{
-				FrPixState ns = st;
-				float m2x, m2y, qx, qy, qw, wcol, gop;
-				fr_pair_backward_t<true>(ns, alpha, G, dx, dy, cx, cy, cz, o, r[0], r[1], r[2], g, g, g, bg_dot, ddelx_dx, ddely_dy,
-				                         m2x, m2y, qx, qy, qw, wcol, gop);
-				st.T = has ? ns.T : st.T;
-				st.accum0 = has ? ns.accum0 : st.accum0; st.accum1 = has ? ns.accum1 : st.accum1; st.accum2 = has ? ns.accum2 : st.accum2;
-				st.lastc0 = has ? ns.lastc0 : st.lastc0; st.lastc1 = has ? ns.lastc1 : st.lastc1; st.lastc2 = has ? ns.lastc2 : st.lastc2;
-				st.last_alpha = has ? ns.last_alpha : st.last_alpha;
+#pragma clang fp contract(fast)
+				// backward.cu:978-1038
+				const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+				st.T = st.T * inv;
+				const float ola = 1.f - st.last_alpha;
+				st.accum0 = st.last_alpha * st.lastc0 + ola * st.accum0; st.lastc0 = r[0];
+				st.accum1 = st.last_alpha * st.lastc1 + ola * st.accum1; st.lastc1 = r[1];
+				st.accum2 = st.last_alpha * st.lastc2 + ola * st.accum2; st.lastc2 = r[2];
+				float dL_dalpha = ((r[0] - st.accum0) * g + (r[1] - st.accum1) * g + (r[2] - st.accum2) * g) * st.T;
+				st.last_alpha = alpha;
+				if (bg_dot != 0.f) dL_dalpha += (-st.T_final * inv) * bg_dot;
+				const float w = a_un * dL_dalpha;                                     // opacity * G * dL_dalpha
+				const float w2 = w * w;
+				float u[5];
+				u[0] = hcx * dx + (hcx * dx + ncy * dy);                              // -(cx dx + cy dy)
+				u[1] = 2.0f * (hcz * dy) + ncy * dx;                                  // -(cz dy + cy dx)
+				u[2] = dx * dx; u[3] = dx * dy; u[4] = dy * dy;
 				float leaf2[C];
 #pragma unroll
 				for (int q = 0; q < 3; q++)
 				{
-					const float l = r[3 + q * 5 + 0] * m2x + r[3 + q * 5 + 1] * m2y + r[3 + q * 5 + 2] * qx
-					              + r[3 + q * 5 + 3] * qy + r[3 + q * 5 + 4] * qw;
+					const float l = r[3 + q * 5 + 0] * u[0] + r[3 + q * 5 + 1] * u[1] + r[3 + q * 5 + 2] * u[2]
+					              + r[3 + q * 5 + 3] * u[3] + r[3 + q * 5 + 4] * u[4];
 					leaf2[q] = l * l;
 				}
-				leaf2[3] = gop * gop;
+				leaf2[3] = r[KO];
 				if constexpr (C == 11)
 				{
 #pragma unroll
 					for (int q = 0; q < 7; q++)
 					{
-						const float l = r[18 + q * 3 + 0] * qx + r[18 + q * 3 + 1] * qy + r[18 + q * 3 + 2] * qw;
+						const float l = r[18 + q * 3 + 0] * u[2] + r[18 + q * 3 + 1] * u[3] + r[18 + q * 3 + 2] * u[4];
 						leaf2[4 + q] = l * l;
 					}
 				}
 				if constexpr (HAS_HINV)
 				{
-					float add = 0.f;
+					float add = FOLD3 ? leaf2[3] : leaf2[3] * r[HO + 3];
 #pragma unroll
-					for (int c = 0; c < C; c++) add += leaf2[c] * r[HO + c];
-					score += has ? add : 0.f;
+					for (int c = 0; c < C; c++)
+						if (c != 3) add += leaf2[c] * r[HO + c];
+					score += has ? w2 * add : 0.f;
 				}
 				if constexpr (HAS_OUTH)
 				{
 					if (has)
 					{
 #pragma unroll
-						for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], leaf2[c]);
+						for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], w2 * leaf2[c]);
 					}
 				}
 			}
@@ -1370,7 +1406,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v2(FrParams p, FrFis
 	float ws = wave_sum(score);
 #ifdef FR_LOOPSTATS
 	if (f.debug_mode >= 2)
-		ws = f.debug_mode == 2 ? (float)dbg_p1 : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_steps : f.debug_mode == 5 ? (float)dbg_hits : (float)wcnt;
+		ws = f.debug_mode == 2 ? (float)dbg_p1 : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_steps : f.debug_mode == 5 ? (float)dbg_hits : f.debug_mode == 7 ? (float)dbg_p1any : f.debug_mode == 8 ? (float)dbg_p1con : (float)wcnt;
 #endif
 	if (lane == 0) s_red[wave] = ws;
 	__syncthreads();
