@@ -1034,7 +1034,7 @@ __device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_fl
 // (ds_add_f32), and the lane that owns an entry then issues ONE global atomic per column for the whole wave -- the
 // reference issues one per pixel per column.
 template <int C, bool HAS_HINV, bool HAS_OUTH>
-__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C == 4 ? 4 : 2))) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C == 4 ? (HAS_OUTH ? 4 : 5) : 2))) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
                                                                uint8_t* __restrict__ fallback)
 {
 	__shared__ float s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];
