@@ -2046,6 +2046,27 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 }
 
 // Launches cov3d, preprocess, scan, scatter, sort for V views.  p must carry the carved buffers.
+// One side stream per host thread for the fork/join inside fr_bin_pipeline (created on first use, lives with the thread).
+struct FrSideStream {
+	hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; int device = -1;
+};
+static FrSideStream& fr_side_stream()
+{
+	static thread_local FrSideStream ss;
+	int dev = -1;
+	(void)hipGetDevice(&dev);
+	if (ss.device != dev)
+	{
+		if (ss.ok) { (void)hipEventDestroy(ss.fork); (void)hipEventDestroy(ss.join); (void)hipStreamDestroy(ss.stream); }
+		ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess
+		     && hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess
+		     && hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+		ss.device = dev;
+		(void)hipGetLastError();
+	}
+	return ss;
+}
+
 static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 {
 	int rc;
@@ -2072,14 +2093,20 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
 	hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
+	// The three sort tiers touch disjoint tile segments.  The 1024-thread tier has few, long-running workgroups (one per
+	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
+	FrSideStream& side = fr_side_stream();
+	const bool forked = side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
+	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
+	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p);
+	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
+	if (forked && hipEventRecord(side.join, side.stream) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipEventRecord(join) failed");
 	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
 	const int mid_blocks = p.T * p.V < 2048 ? p.T * p.V : 2048;
 	hipLaunchKernelGGL(k_sort_mid_tiles, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_mid_tiles"))) return rc;
-	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
-	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, s, p);
-	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
+	if (forked && hipStreamWaitEvent(s, side.join, 0) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipStreamWaitEvent(join) failed");
 	return FR_OK;
 }
 
