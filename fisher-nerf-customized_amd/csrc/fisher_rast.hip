@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 			fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
 			float A[3][5];
 			float B[6][3];
-			fr_mean_jacobian(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
+			fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
 			// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
 			// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
 #pragma unroll
@@ -1277,6 +1277,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 			// Row by row: power(dx, dy) >= thr  <=>  cx dx^2 + 2 cy dy dx + (cz dy^2 + 2 thr) <= 0, an interval in dx
 			// (d = mean - pixel).  Widened by 1 % + 0.01 px, so it stays a superset of the exact test done in the walk.
 			const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
+			const float racx = __builtin_amdgcn_rcpf(acx);
 #pragma unroll
 			for (unsigned r = 0; r < 4; r++)
 			{
@@ -1289,8 +1290,9 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 					const float cq = acz * dy * dy + 2.0f * athr;
 					const float disc = hb * hb - acx * cq;             // (b^2 - 4ac) / 4
 					any_px = any_px && (disc >= 0.f);
-					const float sq = sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
-					const float dlo = (-hb - sq) / acx, dhi = (-hb + sq) / acx;   // dx in [dlo, dhi]
+					// approximate sqrt / reciprocal (1 ulp): the interval is widened by 1 % + 0.01 px anyway
+					const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
+					const float dlo = (-hb - sq) * racx, dhi = (-hb + sq) * racx;   // dx in [dlo, dhi]
 					lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;               // pixel x = mean.x - dx
 				}
 				const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, 15.f);

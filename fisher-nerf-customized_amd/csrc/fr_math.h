@@ -152,6 +152,16 @@ FR_HD void fr_cov3d(fr_f3 scale, float mod, fr_f4 rot, float* cov3D)
 #undef FR_SIG
 }
 
+// Division policy of the Jacobian helpers: IEEE `/` by default (the single-view rasteriser and the host harness); the
+// Fisher scorer, whose bar is 1e-4 on the scores, instantiates them with FAST = true: one v_rcp_f32 (1 ulp) + multiply.
+template <bool FAST> FR_HD float fr_divt(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (FAST) return a * __builtin_amdgcn_rcpf(b);
+#endif
+	return a / b;
+}
+
 // ---- forward.cu:74-113 / backward.cu:300-333: shared front half of computeCov2D ----------------------
 struct fr_cov2d {
 	float tx, ty, tz;       // camera-space mean after the fov clamp
@@ -162,21 +172,22 @@ struct fr_cov2d {
 	float cov00, cov01, cov11; // before the +0.3 low-pass
 };
 
+template <bool FAST = false>
 FR_HD void fr_cov2d_setup(fr_f3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
                           const float* cov3D, const float* view, fr_cov2d& c)
 {
 	fr_f3 t = fr_xform4x3(mean, view);
 	const float limx = 1.3f * tan_fovx;
 	const float limy = 1.3f * tan_fovy;
-	c.txtz = t.x / t.z;
-	c.tytz = t.y / t.z;
+	c.txtz = fr_divt<FAST>(t.x, t.z);
+	c.tytz = fr_divt<FAST>(t.y, t.z);
 	t.x = fminf(limx, fmaxf(-limx, c.txtz)) * t.z;
 	t.y = fminf(limy, fmaxf(-limy, c.tytz)) * t.z;
 	c.tx = t.x; c.ty = t.y; c.tz = t.z;
-	const float J00 = focal_x / t.z;
-	const float J02 = -(focal_x * t.x) / (t.z * t.z);
-	const float J11 = focal_y / t.z;
-	const float J12 = -(focal_y * t.y) / (t.z * t.z);
+	const float J00 = fr_divt<FAST>(focal_x, t.z);
+	const float J02 = fr_divt<FAST>(-(focal_x * t.x), (t.z * t.z));
+	const float J11 = fr_divt<FAST>(focal_y, t.z);
+	const float J12 = fr_divt<FAST>(-(focal_y * t.y), (t.z * t.z));
 	for (int cc = 0; cc < 3; cc++)
 		for (int r = 0; r < 3; r++)
 			c.Wc[cc][r] = view[cc + 4 * r];
@@ -328,6 +339,7 @@ FR_HD fr_f3 fr_sh_to_rgb(int deg, fr_f3 pos, fr_f3 campos, const float* sh, uint
 // =====================================================================================================
 
 // backward.cu:335-407: (dL_dconic.x,.y,.w) -> dL_dcov3D[6] and the covariance part of dL_dmean
+template <bool FAST = false>
 FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_fovx, float tan_fovy,
                              const float* view, float dcx, float dcy, float dcw, fr_f3& dmean, float* dcov)
 {
@@ -338,7 +350,7 @@ FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_
 	const float a = c.cov00 + 0.3f, b = c.cov01, cc = c.cov11 + 0.3f;
 	const float denom = a * cc - b * b;
 	float dL_da = 0, dL_db = 0, dL_dc = 0;
-	const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+	const float denom2inv = fr_divt<FAST>(1.0f, (denom * denom) + 0.0000001f);
 	const float* T0 = c.T0; const float* T1 = c.T1;
 	if (denom2inv != 0)
 	{
@@ -374,7 +386,7 @@ FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_
 	const float dL_dJ02 = c.Wc[2][0] * dL_dT00 + c.Wc[2][1] * dL_dT01 + c.Wc[2][2] * dL_dT02;
 	const float dL_dJ11 = c.Wc[1][0] * dL_dT10 + c.Wc[1][1] * dL_dT11 + c.Wc[1][2] * dL_dT12;
 	const float dL_dJ12 = c.Wc[2][0] * dL_dT10 + c.Wc[2][1] * dL_dT11 + c.Wc[2][2] * dL_dT12;
-	const float tz = 1.f / c.tz;
+	const float tz = fr_divt<FAST>(1.f, c.tz);
 	const float tz2 = tz * tz;
 	const float tz3 = tz2 * tz;
 	const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
@@ -387,10 +399,11 @@ FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_
 }
 
 // backward.cu:557-574: dL_dmean3D += Mp * (dL_dmean2D.x, dL_dmean2D.y); returns Mp as 3 rows of 2
+template <bool FAST = false>
 FR_HD void fr_proj_jacobian(fr_f3 m, const float* proj, float Mp[3][2])
 {
 	fr_f4 m_hom = fr_xform4x4(m, proj);
-	float m_w = 1.0f / (m_hom.w + 0.0000001f);
+	float m_w = fr_divt<FAST>(1.0f, m_hom.w + 0.0000001f);
 	float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
 	float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
 	Mp[0][0] = (proj[0] * m_w - proj[3] * mul1); Mp[0][1] = (proj[1] * m_w - proj[3] * mul2);
@@ -436,14 +449,15 @@ FR_HD void fr_cov3d_backward(fr_f3 scale, float mod, fr_f4 rot, const float* dco
 
 // Jacobian of the camera-frame mean gradient: dL_dmean3D = A * (m2x, m2y, cx, cy, cw)
 // A is 3 rows x 5 columns.  Optionally also B = d(dL_dcov3D)/d(cx,cy,cw) (6x3).
+template <bool FAST = false>
 FR_HD void fr_mean_jacobian(fr_f3 mean, const float* cov3D, const float* view, const float* proj,
                             float focal_x, float focal_y, float tan_fovx, float tan_fovy,
                             float A[3][5], float (*B)[3])
 {
 	fr_cov2d c;
-	fr_cov2d_setup(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c);
+	fr_cov2d_setup<FAST>(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c);
 	float Mp[3][2];
-	fr_proj_jacobian(mean, proj, Mp);
+	fr_proj_jacobian<FAST>(mean, proj, Mp);
 	for (int k = 0; k < 3; k++) { A[k][0] = Mp[k][0]; A[k][1] = Mp[k][1]; }
 #if defined(__HIPCC__)
 #pragma unroll
@@ -451,7 +465,7 @@ FR_HD void fr_mean_jacobian(fr_f3 mean, const float* cov3D, const float* view, c
 	for (int j = 0; j < 3; j++)
 	{
 		fr_f3 dm; float dcov[6];
-		fr_cov2d_backward(c, focal_x, focal_y, tan_fovx, tan_fovy, view,
+		fr_cov2d_backward<FAST>(c, focal_x, focal_y, tan_fovx, tan_fovy, view,
 		                  j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, dm, dcov);
 		A[0][2 + j] = dm.x; A[1][2 + j] = dm.y; A[2][2 + j] = dm.z;
 		if (B)
