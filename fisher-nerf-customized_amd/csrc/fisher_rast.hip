@@ -66,6 +66,9 @@ static int fr_check_launch(const char* what)
 // (negative hx: nowhere; +inf: unknown, treat as everywhere).
 struct FrSplat { float x, y, cx, cy, cz, o, depth; uint32_t ext; };
 
+// One visible (view, Gaussian) as k_preprocess_views hands it to k_scatter_vis: everything the key scatter needs.
+struct FrVisEntry { uint32_t idx, depth_bits, xy0, xy1; };   // tile rect: xy0 = x0 | y0 << 16, xy1 = x1 | y1 << 16
+
 struct FrParams {
 	int P, V, W, H;
 	uint32_t gx, gy;
@@ -90,6 +93,10 @@ struct FrParams {
 	int* status;                 // [4]
 	int* vis_count;              // [V] or null
 	int* num_rendered;           // [V] or null
+	// multi-view front end (k_preprocess_views / k_scatter_vis), null on the single-view API
+	struct FrVisEntry* vis_list; // [V][blocks][FR_THREADS * G] compacted visible splats of each preprocess workgroup
+	uint32_t* vis_n;             // [V][blocks] their number
+	int VC;                      // views per preprocess workgroup
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -420,6 +427,168 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 						p.keys[slot] = hi | (uint32_t)i;
 					}
 			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-view front end of the Fisher path (same camera, one rigid transform per candidate view).
+// k_preprocess is VALU-bound there: only ~1/4 of the (view, Gaussian) pairs are visible, so the ~400-instruction
+// projection ran with a quarter of its lanes.  Here a workgroup takes FR_THREADS*G Gaussians x VC views:
+//   phase A  every thread holds one Gaussian and runs the near-plane test (the first test of preprocessCUDA,
+//            forward.cu:181-199) for the VC views; survivors are compacted into an LDS pair list (wave ballot);
+//   phase B  the pair list is processed densely: projection, conic, radius, tile rect (fr_preprocess_one), the
+//            32-byte splat record, the per-(view, tile) LDS histogram, and one 16-byte entry per VISIBLE pair in
+//            this workgroup's compact list, which is all k_scatter_vis reads (no radii array, no idle lanes).
+// The arithmetic per pair is fr_preprocess_one's, so radii / rects / depths are bit-identical to k_preprocess.
+__global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p)
+{
+	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12]
+	const int VC = p.VC;
+	uint32_t* hist = fr_dyn_lds;
+	uint32_t* pairs = hist + (size_t)VC * p.T;
+	float* s_wm = (float*)(pairs + FR_THREADS * VC);
+	__shared__ uint32_t s_np;
+	__shared__ uint32_t s_n[16];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int v0 = blockIdx.y * VC;
+	const int nv = min(VC, p.V - v0);
+	const uint32_t nblk = gridDim.x;
+	const uint32_t cap = (uint32_t)(FR_THREADS * p.G);
+	for (int t = tid; t < nv * p.T; t += FR_THREADS) hist[t] = 0;
+	const bool has_w2c = p.w2c != nullptr;
+	if (has_w2c) for (int t = tid; t < nv * 12; t += FR_THREADS) s_wm[t] = p.w2c[16 * (size_t)(v0 + t / 12) + (t % 12)];
+	if (tid < 16) s_n[tid] = 0;
+	if (tid == 0) s_np = 0;
+	float vm[16], pm[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	__syncthreads();
+	for (int g = 0; g < p.G; g++)
+	{
+		const int i0 = (blockIdx.x * p.G + g) * FR_THREADS;
+		if (i0 >= p.P) break;
+		// ---- phase A
+		{
+			const int i = i0 + tid;
+			const bool live = i < p.P;
+			fr_f3 pw = { 0.f, 0.f, 0.f };
+			if (live) pw = fr_f3{ p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+			for (int vv = 0; vv < nv; vv++)
+			{
+				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, s_wm + 12 * vv) : pw;
+				const fr_f3 p_view = fr_xform4x3(po, vm);
+				const bool keep = live && !(p_view.z <= 0.001f);
+				const unsigned long long m = __ballot(keep);
+				if (m)
+				{
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd(&s_np, (uint32_t)__popcll(m));
+					base = __builtin_amdgcn_readfirstlane(base);
+					if (keep) pairs[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)tid | ((uint32_t)vv << 8);
+				}
+			}
+		}
+		__syncthreads();
+		// ---- phase B
+		const uint32_t np = s_np;
+		for (uint32_t e = tid; e < np; e += FR_THREADS)
+		{
+			const uint32_t pr = pairs[e];
+			const int i = i0 + (int)(pr & 255u);
+			const int vv = (int)(pr >> 8);
+			const int v = v0 + vv;
+			const fr_f3 pw = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+			float wm[12];
+			if (has_w2c)
+			{
+#pragma unroll
+				for (int k = 0; k < 12; k++) wm[k] = s_wm[12 * vv + k];
+			}
+			const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+			float c3[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
+			const fr_splat s = fr_preprocess_one(po, c3, vm, pm, p.W, p.H, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.gx, p.gy);
+			if (s.radius > 0)
+			{
+				const float o = p.opac[i];
+				float4* dst = (float4*)(p.splat + (size_t)v * p.P + i);
+				dst[0] = make_float4(s.px, s.py, s.conx, s.cony);
+				dst[1] = make_float4(s.conz, o, s.depth, __uint_as_float(fr_alpha_extent(s.conx, s.cony, s.conz, o)));
+				uint32_t* h = hist + (size_t)vv * p.T;
+				for (uint32_t y = s.rect.y0; y < s.rect.y1; y++)
+					for (uint32_t x = s.rect.x0; x < s.rect.x1; x++)
+						atomicAdd(&h[y * p.gx + x], 1u);
+				const uint32_t slot = atomicAdd(&s_n[vv], 1u);
+				FrVisEntry en;
+				en.idx = (uint32_t)i; en.depth_bits = fr_as_u32(s.depth);
+				en.xy0 = s.rect.x0 | (s.rect.y0 << 16); en.xy1 = s.rect.x1 | (s.rect.y1 << 16);
+				*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + slot) = *(const uint4*)&en;
+			}
+		}
+		__syncthreads();
+		if (tid == 0) s_np = 0;
+		// (the next phase A only appends after its own ballots; the barrier at its end orders the reset)
+		__syncthreads();
+	}
+	for (int vv = 0; vv < nv; vv++)
+	{
+		const int v = v0 + vv;
+		uint32_t* cnt = p.tile_cnt + (size_t)v * p.T;
+		const uint32_t* h = hist + (size_t)vv * p.T;
+		for (int t = tid; t < p.T; t += FR_THREADS)
+		{
+			const uint32_t c = h[t];
+			if (c) p.blk_base[((size_t)v * nblk + blockIdx.x) * p.T + t] = atomicAdd(&cnt[t], c);
+		}
+	}
+	if (tid < nv)
+	{
+		const int v = v0 + tid;
+		p.vis_n[(size_t)v * nblk + blockIdx.x] = s_n[tid];
+		if (p.vis_count && s_n[tid]) atomicAdd(&p.vis_count[v], (int)s_n[tid]);
+	}
+}
+
+// Key scatter of the multi-view front end: one workgroup per (preprocess workgroup, view), all lanes busy.
+__global__ __launch_bounds__(FR_THREADS) void k_scatter_vis(FrParams p)
+{
+	extern __shared__ uint32_t fr_dyn_lds[];     // s_cnt[T] | s_base[T]
+	uint32_t* s_cnt = fr_dyn_lds;
+	uint32_t* s_base = fr_dyn_lds + p.T;
+	if (p.status[1]) return;
+	const int tid = threadIdx.x;
+	const int v = blockIdx.y;
+	const uint32_t nblk = gridDim.x;
+	const uint32_t n = p.vis_n[(size_t)v * nblk + blockIdx.x];
+	if (n == 0) return;
+	const uint32_t* off = p.tile_off + (size_t)v * p.T;
+	const uint32_t* bb = p.blk_base + ((size_t)v * nblk + blockIdx.x) * p.T;
+	for (int t = tid; t < p.T; t += FR_THREADS) { s_cnt[t] = 0; s_base[t] = off[t] + bb[t]; }   // bb[t] is only used where this workgroup counted > 0
+	__syncthreads();
+	const uint4* list = (const uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * (size_t)(FR_THREADS * p.G));
+	constexpr int NB = 4;
+	for (uint32_t e0 = 0; e0 < n; e0 += NB * FR_THREADS)
+	{
+		uint4 en[NB];
+#pragma unroll
+		for (int b = 0; b < NB; b++)
+		{
+			const uint32_t e = e0 + b * FR_THREADS + tid;
+			en[b] = e < n ? list[e] : make_uint4(0u, 0u, 0u, 0u);       // empty rect
+		}
+#pragma unroll
+		for (int b = 0; b < NB; b++)
+		{
+			const uint64_t key = ((uint64_t)en[b].y << 32) | en[b].x;
+			const uint32_t x0 = en[b].z & 0xffffu, y0 = en[b].z >> 16, x1 = en[b].w & 0xffffu, y1 = en[b].w >> 16;
+			for (uint32_t y = y0; y < y1; y++)
+				for (uint32_t x = x0; x < x1; x++)
+				{
+					const uint32_t t = y * p.gx + x;
+					p.keys[s_base[t] + atomicAdd(&s_cnt[t], 1u)] = key;
+				}
 		}
 	}
 }
@@ -1942,9 +2111,22 @@ static inline int fr_pick_G(long long P, long long V)
 	long long gwant = (P * V) / ((long long)FR_THREADS * 2048);
 	return (int)(gwant < 1 ? 1 : (gwant > FR_G_MAX ? FR_G_MAX : gwant));
 }
+// multi-view front end: 256*G Gaussians x VC views per workgroup
+static inline int fr_pick_G_views(long long P)
+{
+	long long gwant = P / ((long long)FR_THREADS * 256);     // ~256 workgroups along P at least
+	return (int)(gwant < 1 ? 1 : (gwant > 8 ? 8 : gwant));
+}
+static inline int fr_pick_VC(long long T)
+{
+	long long vc = 8192 / (T < 1 ? 1 : T);
+	return (int)(vc < 1 ? 1 : (vc > 8 ? 8 : vc));
+}
 static inline long long fr_preprocess_blocks(long long P, long long V)
 {
-	const long long per_block = (long long)FR_THREADS * fr_pick_G(P, V);
+	// the larger of the two decompositions fr_bin_pipeline can pick (blk_base is sized with it)
+	const long long g = fr_pick_G(P, V) < fr_pick_G_views(P) ? fr_pick_G(P, V) : fr_pick_G_views(P);
+	const long long per_block = (long long)FR_THREADS * g;
 	return (P + per_block - 1) / per_block;
 }
 
@@ -2035,6 +2217,7 @@ static int fr_validate(const fr_raster_cfg* cfg, const fr_gaussians* g, const ch
 
 static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gaussians* g, int V)
 {
+	p.vis_list = nullptr; p.vis_n = nullptr; p.VC = 1;
 	memset(&p, 0, sizeof(p));
 	p.P = cfg->P; p.V = V; p.W = cfg->image_width; p.H = cfg->image_height;
 	p.gx = (uint32_t)((p.W + 15) / 16); p.gy = (uint32_t)((p.H + 15) / 16); p.T = (int)(p.gx * p.gy);
@@ -2084,16 +2267,29 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 		if ((rc = fr_check_launch("k_cov3d"))) return rc;
 		p.cov3D = p.cov3D_out;
 	}
-	p.G = fr_pick_G(P, p.V);
+	const bool multi = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;
+	p.G = multi ? fr_pick_G_views(P) : fr_pick_G(P, p.V);
+	p.VC = fr_pick_VC(p.T);
 	const int per_block = FR_THREADS * p.G;
 	dim3 gridP((P + per_block - 1) / per_block, p.V);
 	const size_t hist_lds = p.T <= FR_MAX_LDS_TILES ? (size_t)p.T * 4 : 16;
-	hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
-	if ((rc = fr_check_launch("k_preprocess"))) return rc;
+	if (multi)
+	{
+		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
+		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC) * 4;
+		hipLaunchKernelGGL(k_preprocess_views, gridV, dim3(FR_THREADS), lds, s, p);
+		if ((rc = fr_check_launch("k_preprocess_views"))) return rc;
+	}
+	else
+	{
+		hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
+		if ((rc = fr_check_launch("k_preprocess"))) return rc;
+	}
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
 	                   p.key_capacity, p.status, p.num_rendered, p.big_list);
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
-	hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
+	if (multi) hipLaunchKernelGGL(k_scatter_vis, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
+	else hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
 	// The three sort tiers touch disjoint tile segments.  The 1024-thread tier has few, long-running workgroups (one per
 	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
@@ -2239,7 +2435,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 
 // ---- fused Fisher scorer ---------------------------------------------------------------------------------
 struct FrFisherLayout {
-	size_t radii, splat, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, vis_n, splat, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
@@ -2247,7 +2443,11 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
 	const size_t VP = (size_t)(V * P);
 	size_t o = 0;
-	L.radii = o; o = fr_align(o + VP * 4);
+	// radii [V][P] int32 (single-pass front end, images beyond FR_MAX_LDS_TILES tiles) and the compact visible lists
+	// [V][blocks][256 G] x 16 B of the multi-view front end share one region: a launch runs one or the other
+	const size_t nblk_v = (size_t)((P + FR_THREADS * fr_pick_G_views(P) - 1) / (FR_THREADS * fr_pick_G_views(P)));
+	L.radii = o; o = fr_align(o + (size_t)V * nblk_v * (size_t)(FR_THREADS * fr_pick_G_views(P)) * sizeof(FrVisEntry));
+	L.vis_n = o; o = fr_align(o + (size_t)V * nblk_v * 4);
 	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
@@ -2332,6 +2532,8 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	fr_fill_params(p, cfg, g, V);
 	p.w2c = fc->w2c;
 	p.radii = (int*)(ws + L.radii);
+	p.vis_list = (FrVisEntry*)(ws + L.radii);
+	p.vis_n = (uint32_t*)(ws + L.vis_n);
 	p.splat = (FrSplat*)(ws + L.splat);
 	p.cov3D_out = (float*)(ws + L.cov3D);
 	p.tile_cnt = (uint32_t*)(ws + L.tile_cnt);
