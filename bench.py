@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--views", type=int, default=64, help="candidate views per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--columns", type=int, default=4)
-    ap.add_argument("--cpu-views", type=int, default=4, help="views of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-views", type=int, default=12, help="views of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,12 +159,19 @@ def main():
         B_view = (12 * P + 44 * vis_count.mean() + 24 * num_rendered.mean() + 40 * num_rendered.mean() +
                   40 * num_rendered.mean() + 24 * W * H + 8 * W * H + 4 * C * P)
         traffic = None
+        valu = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v2.json")
         if os.path.exists(pmc_file):
             try:
                 pm = json.load(open(pmc_file))
                 if pm.get("gaussians") == P and pm.get("views") == V // launches_per_step and pm.get("size") == W and pm.get("columns") == C:
                     traffic = pm.get("hbm_bytes_per_launch")
+                    if pm.get("SQ_INSTS_VALU") and kern_ms == kern_ms:
+                        # the kernel's real limiter: wave-level VALU instructions (one per 4 cycles per SIMD) against the
+                        # 1024 SIMDs of the chip at the nominal 2.4 GHz peak clock (a lower bound on the busy fraction)
+                        valu = {"insts_per_launch": pm["SQ_INSTS_VALU"], "simds": 1024, "clock_ghz": 2.4,
+                                "issue_frac": pm["SQ_INSTS_VALU"] * 4 / (1024 * kern_ms * 1e-3 * 2.4e9),
+                                "source": "profiles/pmc_k_fisher_tile_v2.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
             except Exception:
                 traffic = None
         out = {
@@ -180,7 +187,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_fisher_tile_v2", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes, "launches_per_step": launches_per_step,
-                         "views_per_launch": V // launches_per_step},
+                         "views_per_launch": V // launches_per_step, "valu": valu},
             "path": {"bytes_per_view": float(B_view), "achieved_GBps": float(B_view * views_per_s / world / 1e9),
                      "frac_of_hbm_peak": float(B_view * views_per_s / world / 1e9 / HBM_PEAK_GBS)},
         }
