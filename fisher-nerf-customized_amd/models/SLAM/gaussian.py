@@ -15,12 +15,15 @@ What changes underneath: instead of one rasteriser forward + backward(power=2) +
 per-view allocations and two host syncs, every call batches its views through FisherScorer
 (fisher_rast/ops.py -> fr_fisher_views) and synchronises once when the scores are brought to the host.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 from fisher_rast.ops import FisherScorer
+from models.SLAM.utils.common_utils import checkpoint_time_idx, load_params_ckpt, save_params, save_params_ckpt
 from models.SLAM.utils.recon_helpers import setup_camera
 from models.SLAM.utils.slam_helpers import transformed_params2rendervar, transformed_params2depthplussilhouette
 
@@ -145,6 +148,7 @@ class GaussianSLAM(FisherOps):
         self.intrinsics = None if intrinsics is None else torch.as_tensor(np.asarray(intrinsics)).float().to(self.device)
         self.params = {}
         self.variables = {}
+        self.checkpoint_extras = {}
         self.cam = None
         self.frame_idx = 0
         self.keyframe_list = []
@@ -158,11 +162,32 @@ class GaussianSLAM(FisherOps):
 
     # -- construction helpers (checkpoint format: common_utils.py:45-59, gaussian.py:156-168) ----------
     def load_params(self, params):
-        if isinstance(params, str):
-            params = dict(np.load(params))
+        """`params`: a dict of arrays / tensors, or the path of a `params{t}.npz` / `params.npz` checkpoint written by the
+        reference (common_utils.py:35-59).  A path is read the way tester_gaussians_navigation.py:2745-2760 does: the extras
+        "Uncertainty" / "occ_map" are kept aside, the densification statistics are reset, and
+        `keyframe_time_indices{t}.npy` next to `eval_dir` is picked up when it exists."""
+        if isinstance(params, (str, os.PathLike)):
+            weight_file = os.fspath(params)
+            self.params, self.checkpoint_extras = load_params_ckpt(weight_file, device=self.device)
+            n = self.params['means3D'].shape[0]
+            for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep'):
+                self.variables[k] = torch.zeros(n, device=self.device, dtype=torch.float32)
+            t = checkpoint_time_idx(weight_file)
+            if t is not None:
+                self.frame_idx = t
+                kf_file = os.path.join(self.eval_dir or os.path.dirname(weight_file), f"keyframe_time_indices{t}.npy")
+                if os.path.exists(kf_file):
+                    self.keyframe_time_indices = np.load(kf_file).tolist()
+            return self
         self.params = {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).float().to(self.device)
                        for k, v in params.items()}
         return self
+
+    def save_params_ckpt(self, output_dir, time_idx=None, **extra_args):
+        """Writes `params{time_idx}.npz` (or `params.npz`) in the reference's format."""
+        if time_idx is None:
+            return save_params(self.params, output_dir)
+        return save_params_ckpt(self.params, output_dir, time_idx, **extra_args)
 
     def set_camera(self, width, height, intrinsics):
         k = np.asarray(intrinsics.cpu() if isinstance(intrinsics, torch.Tensor) else intrinsics)

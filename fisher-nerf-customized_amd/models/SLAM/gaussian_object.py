@@ -7,7 +7,10 @@
       cur_H and need K backward passes with random upstream gradients on one forward, so they run through the drop-in
       autograd rasteriser exactly as the reference does (forward once, `backward(gradient=z, retain_graph=...)` K times on
       the power-2 rasteriser, squares of those gradients averaged -- the reference's own quirk).
+  estimate_block_JtJ (2111-2176), compute_H_train_blocks (1572-1585), pose_eval_popgs_blocks (1660-1704),
+  t_opt_blocks / d_opt_blocks (1721-1732): the per-splat d x d block form of the same criteria (d <= 11), same route.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -93,6 +96,115 @@ class ObjectFisherOps(FisherOps):
             else:
                 raise ValueError("criterion must be 'topt' or 'dopt'")
             scores.append(s)
+            c2ws.append(c2w)
+        return torch.tensor(scores), torch.stack(c2ws)
+
+    # ---- block form (gaussian_object.py:2111-2176, 1572-1585, 1660-1732) ------------------------------------------
+    @torch.enable_grad()
+    def estimate_block_JtJ(self, w2c, K: int = 2, use_rot: bool = True, use_scale: bool = True, use_opacity: bool = True,
+                           zs=None):
+        """Returns (H_blocks [Nv, d, d] / K, vis_idx [Nv]): per visible splat the outer product of its power-2 gradient
+        row [mean3 | opacity | rot4 | scale3] (columns present as the flags say), averaged over K random upstream draws.
+        `zs` (optional list of K [3,H,W] tensors) replaces the reference's `torch.randn_like(im)` draws."""
+        dev = self._device()
+        w2c = self._as_w2c(w2c)
+        p = self.params
+        with torch.no_grad():
+            pts = p['means3D']
+            pts4 = torch.cat([pts, torch.ones(pts.shape[0], 1, device=dev, dtype=torch.float32)], dim=1)
+            transformed_pts = (w2c @ pts4.T).T[:, :3].contiguous()
+            rotations = F.normalize(p['unnorm_rotations'])
+            opacities = torch.sigmoid(p['logit_opacities'])
+            scales = torch.exp(p['log_scales'])
+            if scales.shape[-1] == 1:
+                scales = scales.repeat(1, 3)
+            colors = p['rgb_colors']
+        rvars = {
+            'means3D': transformed_pts.requires_grad_(True),
+            'rotations': rotations.detach().clone().requires_grad_(use_rot),
+            'scales': scales.detach().clone().requires_grad_(use_scale),
+            'opacities': opacities.detach().clone().requires_grad_(use_opacity),
+            'colors_precomp': colors.detach(),
+            'means2D': torch.zeros_like(transformed_pts, requires_grad=True, device=dev),
+        }
+        im, radius, _ = Renderer(raster_settings=self.cam, backward_power=2)(**rvars)
+        vis_idx = torch.where(radius > 0)[0]
+        Nv = vis_idx.numel()
+
+        def rows():
+            cols = [rvars['means3D'].grad]
+            if use_opacity: cols.append(rvars['opacities'].grad)
+            if use_rot: cols.append(rvars['rotations'].grad)
+            if use_scale: cols.append(rvars['scales'].grad)
+            return torch.cat([c.reshape(c.shape[0], -1) for c in cols], dim=1)
+
+        def zero():
+            for v in rvars.values():
+                if isinstance(v, torch.Tensor) and v.grad is not None:
+                    v.grad.zero_()
+
+        d = 3 + (1 if use_opacity else 0) + (4 if use_rot else 0) + (3 if use_scale else 0)   # the reference finds d with a dummy backward
+        H_blocks = torch.zeros((Nv, d, d), device=im.device, dtype=im.dtype)
+        for k in range(int(K)):
+            z = torch.randn_like(im) if zs is None else zs[k].to(dev)
+            zero()
+            im.backward(gradient=z, retain_graph=(k < K - 1))
+            Gv = rows()[vis_idx, :]
+            H_blocks += Gv.unsqueeze(2) * Gv.unsqueeze(1)
+        zero()
+        return H_blocks / float(K), vis_idx
+
+    def compute_H_train_blocks(self, K: int = 2, **kw):
+        """Sum over keyframes, aligned the reference's way (truncate to the smaller visible count, keep the first index set)."""
+        Hm, vis_ref = None, None
+        for kf in self.keyframe_list:
+            Hb, vis_idx = self.estimate_block_JtJ(kf['est_w2c'], K=K, **kw)
+            if Hm is None:
+                Hm, vis_ref = Hb, vis_idx
+            else:
+                Nv = min(Hm.shape[0], Hb.shape[0])
+                Hm = Hm[:Nv] + Hb[:Nv]
+                vis_ref = vis_ref[:Nv]
+        if Hm is None:
+            raise RuntimeError("No keyframes available for POP-GS prior (blocks).")
+        return Hm, vis_ref
+
+    @staticmethod
+    def t_opt_blocks(Hm_blocks, J_blocks, lam=1e-6):
+        I = torch.eye(Hm_blocks.shape[-1], device=Hm_blocks.device, dtype=Hm_blocks.dtype)
+        invH = torch.linalg.inv(Hm_blocks + J_blocks + lam * I)
+        return -torch.einsum('bii->', invH)
+
+    @staticmethod
+    def d_opt_blocks(Hm_blocks, J_blocks, lam=1e-6):
+        I = torch.eye(Hm_blocks.shape[-1], device=Hm_blocks.device, dtype=Hm_blocks.dtype)
+        Hm = Hm_blocks + lam * I
+        _, log1 = torch.linalg.slogdet(Hm + J_blocks)
+        _, log0 = torch.linalg.slogdet(Hm)
+        return (log1 - log0).sum()
+
+    def pose_eval_popgs_blocks(self, poses, random_gaussian_params=None, criterion: str = "topt", K: int = 6, lam: float = 1e-6,
+                               use_rot=True, use_scale=True, use_opacity=True):
+        kw = dict(use_rot=use_rot, use_scale=use_scale, use_opacity=use_opacity)
+        Hm_blocks, train_vis_idx = self.compute_H_train_blocks(K=K, **kw)
+        train_np = train_vis_idx.detach().cpu().numpy()
+        scores, c2ws = [], []
+        for c2w in poses:
+            c2w = self._as_w2c(c2w)
+            Jb, cur_vis_idx = self.estimate_block_JtJ(torch.linalg.inv(c2w), K=K, **kw)
+            _, idx_train, idx_cur = np.intersect1d(train_np, cur_vis_idx.detach().cpu().numpy(), return_indices=True)
+            if idx_train.size == 0:
+                scores.append(float('-inf')); c2ws.append(c2w)
+                continue
+            Hb = Hm_blocks[torch.from_numpy(idx_train).to(Hm_blocks.device)]
+            J = Jb[torch.from_numpy(idx_cur).to(Jb.device)]
+            if criterion.lower() == "topt":
+                score = self.t_opt_blocks(Hb, J, lam)
+            elif criterion.lower() == "dopt":
+                score = self.d_opt_blocks(Hb, J, lam)
+            else:
+                raise ValueError("criterion must be 'topt' or 'dopt'")
+            scores.append(score.item())
             c2ws.append(c2w)
         return torch.tensor(scores), torch.stack(c2ws)
 

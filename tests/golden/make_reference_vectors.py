@@ -46,3 +46,26 @@ R = torch.tensor(poses[:, :3, :3], dtype=torch.float32)
 out["quat_wxyz"] = matrix_to_quaternion(R).numpy()
 np.savez_compressed(os.path.join(HERE, "reference_pose_helpers.npz"), **out)
 print("written", {k: v.shape for k, v in out.items()})
+
+# ---- checkpoint format: a `params{t}.npz` written by the reference's own save_params_ckpt (common_utils.py:45-59) ----
+import shutil
+import tempfile
+
+from models.SLAM.utils.common_utils import save_params_ckpt              # reference
+
+g = torch.Generator().manual_seed(77)
+N = 24
+ck_params = {
+    'means3D': torch.randn((N, 3), generator=g),
+    'rgb_colors': torch.rand((N, 3), generator=g),
+    'unnorm_rotations': torch.randn((N, 4), generator=g),
+    'logit_opacities': torch.randn((N, 1), generator=g),
+    'log_scales': torch.randn((N, 1), generator=g) - 3.0,
+    'cam_unnorm_rots': torch.randn((1, 4, 5), generator=g),
+    'cam_trans': torch.randn((1, 3, 5), generator=g),
+}
+tmp = tempfile.mkdtemp()
+save_params_ckpt(ck_params, tmp, 7, Uncertainty=torch.rand((N,), generator=g), occ_map=np.arange(12, dtype=np.float32).reshape(3, 4))
+shutil.copy(os.path.join(tmp, "params7.npz"), os.path.join(HERE, "reference_params7.npz"))
+shutil.rmtree(tmp)
+print("written reference_params7.npz", sorted(np.load(os.path.join(HERE, "reference_params7.npz")).keys()))

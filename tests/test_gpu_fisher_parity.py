@@ -216,6 +216,53 @@ def test_popgs_diag_estimator(config1, gpu, oracle):
     assert scores.shape == (2,) and c2ws.shape == (2, 4, 4)
 
 
+def test_popgs_block_estimator(config1, gpu, oracle):
+    """estimate_block_JtJ (gaussian_object.py:2111-2176): per visible splat the outer product of its power-2 gradient row
+    [mean3 | opacity | rot4 | scale3] under supplied upstream draws; then the block T-/D-opt scores (1660-1732)."""
+    import models.gaussian_slam as mgs
+    c = config1
+    slam = mgs.GaussianObjectSLAM(params=c["params"], intrinsics=c["K"], width=c["W"], height=c["H"], device=gpu)
+    K = 2
+    g = torch.Generator().manual_seed(6)
+    zs = [torch.randn((3, c["H"], c["W"]), generator=g) for _ in range(K)]
+    w2c = torch.linalg.inv(c["c2w"][2].to(gpu))
+    Hb, vis_idx = slam.estimate_block_JtJ(w2c, K=K, zs=zs)
+    from models.SLAM.utils.slam_helpers import transformed_params2rendervar
+    pts = slam.params["means3D"]
+    tp = (w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3]
+    n = {k: v.detach().cpu().numpy() for k, v in transformed_params2rendervar(slam.params, tp).items()}
+    fw = oracle.rasterize_forward(c["ocam"], n["means3D"], n["opacities"], colors_precomp=n["colors_precomp"], scales=n["scales"], rotations=n["rotations"])
+    vis = np.where(fw["radii"] > 0)[0]
+    assert np.array_equal(vis_idx.cpu().numpy(), vis)
+    want = np.zeros((vis.size, 11, 11))
+    for z in zs:
+        gz = oracle.rasterize_backward(c["ocam"], fw, z.numpy(), 2)
+        G = np.concatenate([gz["dL_dmeans3D"], gz["dL_dopacity"].reshape(-1, 1), gz["dL_drotations"], gz["dL_dscales"]], 1).astype(np.float64)[vis]
+        want += G[:, :, None] * G[:, None, :]
+    want /= K
+    assert Hb.shape == (vis.size, 11, 11)
+    assert_close(Hb.cpu().numpy(), want, 4e-4, "block_JtJ", atol_frac=1e-7)
+    # column subsets keep the reference's order [mean | opacity | rot | scale]
+    Hs, _ = slam.estimate_block_JtJ(w2c, K=K, zs=zs, use_rot=False)
+    keep = [0, 1, 2, 3, 8, 9, 10]
+    assert_close(Hs.cpu().numpy(), want[:, keep][:, :, keep], 4e-4, "block_JtJ(no rot)", atol_frac=1e-7)
+    # block criteria against float64 numpy on the same blocks
+    for kf in c["kf_w2c"][:2]:
+        slam.add_keyframe(kf)
+    Hm, tv = slam.compute_H_train_blocks(K=1)
+    assert Hm.shape[1:] == (11, 11) and tv.shape[0] == Hm.shape[0]
+    lam = 1e-3
+    Hm64, J64 = Hm[:64].double().cpu().numpy(), Hb[:64].double().cpu().numpy()
+    I = np.eye(11)
+    t_want = -np.trace(np.linalg.inv(Hm64 + J64 + lam * I), axis1=1, axis2=2).sum()
+    d_want = (np.linalg.slogdet(Hm64 + lam * I + J64)[1] - np.linalg.slogdet(Hm64 + lam * I)[1]).sum()
+    t_got = float(slam.t_opt_blocks(Hm[:64].double(), Hb[:64].double(), lam))
+    d_got = float(slam.d_opt_blocks(Hm[:64].double(), Hb[:64].double(), lam))
+    assert abs(t_got - t_want) <= 1e-8 * abs(t_want) and abs(d_got - d_want) <= 1e-8 * max(1.0, abs(d_want))
+    scores, c2ws = slam.pose_eval_popgs_blocks([p.to(gpu) for p in c["c2w"][:2]], criterion="dopt", K=1, lam=1e-3)
+    assert scores.shape == (2,) and c2ws.shape == (2, 4, 4) and bool(torch.isfinite(scores).all())
+
+
 def _crowded_scene(P, seed):
     """P tiny, faint splats that all project into the 16x16 tile at the image centre of a 48x48 view."""
     rng = np.random.default_rng(seed)
