@@ -53,6 +53,40 @@ def cpu_baseline(P, W, H, seed, n_views, columns):
                 seconds=dt)
 
 
+def gpu_occupancy_frontier(dev, W, H, seed, n_frames=4, n_gaussians=200_000):
+    """The planner-side kernels (fr_occ_update / fr_occ_freespace / fr_occ_frontiers) on the same synthetic frames as
+    the CPU occupancy baseline: ms per map update and per frontier build, map resident, one host sync per build."""
+    from fisher_rast import synthetic
+    from oracle.occupancy_frontier import room_depth           # input generator of the baseline (not the thing measured)
+    from planning import AstarPlanner
+    K = synthetic.intrinsics(W, H)
+    poses = synthetic.candidate_poses(n_frames, seed + 200).numpy().astype(np.float32)
+    pts = synthetic.room_shell(n_gaussians, seed)["means3D"].to(dev)
+    pl = AstarPlanner(device=dev, cell_size=0.05, frontier_select_method="combined")
+    pl.init(torch.eye(4), torch.from_numpy(np.asarray(K, dtype=np.float32)))
+    depths = [torch.from_numpy(room_depth(p, W, H, K)).to(dev) for p in poses]
+    c2ws = [torch.from_numpy(p).to(dev) for p in poses]
+    pl.update_occ_map(depths[0], c2ws[0], 0)                    # warm-up (workspace allocation)
+    pl.init(torch.eye(4), torch.from_numpy(np.asarray(K, dtype=np.float32)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t, (d, c) in enumerate(zip(depths, c2ws)):
+        pl.update_occ_map(d, c, t)
+    torch.cuda.synchronize()
+    t_up = (time.perf_counter() - t0) / n_frames
+    pl.build_frontiers(pts)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fr, free = pl.build_frontiers(pts)
+    torch.cuda.synchronize()
+    t_fr = (time.perf_counter() - t0) / reps
+    return dict(ms_per_update=1e3 * t_up, ms_per_frontier_build=1e3 * t_fr, frames=n_frames,
+                free_cells=int(free.sum()), frontier_cells=0 if fr is None else int(len(fr)),
+                kernels="fr_occ_update / fr_occ_freespace / fr_occ_frontiers (csrc/fisher_occ.hip), wall time incl. host glue")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +230,7 @@ def main():
             # the reference's CPU occupancy / frontier step (planning/astar.py), timed on the same host cores
             from oracle import occupancy_frontier
             out["cpu_occupancy_frontier"] = occupancy_frontier.time_baseline(n_frames=4, W=W, H=H, seed=seed)
+            out["gpu_occupancy_frontier"] = gpu_occupancy_frontier(dev, W, H, seed)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

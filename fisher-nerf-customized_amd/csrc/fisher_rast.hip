@@ -28,6 +28,7 @@
 #include <string.h>
 #include "fr_math.h"
 #include "../../include/fisher_rast.h"
+#include "fr_internal.h"
 
 #define FR_THREADS 256
 #define FR_G_MAX 32                  // upper bound of Gaussians per thread in the per-Gaussian kernels (FrParams::G)
@@ -44,12 +45,12 @@ static thread_local char g_err[512] = "";
 // measurement only: HIP events recorded around the dominant kernel on the stream it is launched on
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static int fr_fail(int code, const char* msg)
+int fr_fail(int code, const char* msg)
 {
 	snprintf(g_err, sizeof(g_err), "%s", msg);
 	return code;
 }
-static int fr_check_launch(const char* what)
+int fr_check_launch(const char* what)
 {
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)

@@ -61,11 +61,26 @@ class FisherCfg(ctypes.Structure):
     ]
 
 
-# every symbol include/fisher_rast.h declares
+class OccCfg(ctypes.Structure):
+    """fr_occ_cfg (include/fisher_occ.h)"""
+    _fields_ = [
+        ("grid_w", ctypes.c_int32),
+        ("grid_h", ctypes.c_int32),
+        ("cell_size", ctypes.c_float),
+        ("center_x", ctypes.c_float),
+        ("center_z", ctypes.c_float),
+        ("height_lower", ctypes.c_float),
+        ("height_upper", ctypes.c_float),
+        ("far_distance", ctypes.c_float),
+    ]
+
+
+# every symbol include/fisher_rast.h and include/fisher_occ.h declare
 EXPORTS = (
     "fr_version", "fr_last_error", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
     "fr_forward", "fr_backward", "fr_fisher_workspace_bytes", "fr_fisher_views",
     "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
+    "fr_occ_workspace_bytes", "fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of",
 )
 
 _lib = None
@@ -122,6 +137,24 @@ def load():
     lib.fr_profile_enable.argtypes = [ctypes.c_int]
     lib.fr_profile_fetch.restype = ctypes.c_int
     lib.fr_profile_fetch.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    occp = ctypes.POINTER(OccCfg)
+    f4, f16 = ctypes.c_float * 4, ctypes.c_float * 16
+    lib.fr_occ_workspace_bytes.restype = ctypes.c_size_t
+    lib.fr_occ_workspace_bytes.argtypes = [occp]
+    lib.fr_occ_update.restype = ctypes.c_int
+    lib.fr_occ_update.argtypes = [occp, _f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(f4), ctypes.POINTER(f16),
+                                  ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _f32p,
+                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.fr_occ_freespace.restype = ctypes.c_int
+    lib.fr_occ_freespace.argtypes = [occp, _f32p, _f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.fr_occ_frontiers.restype = ctypes.c_int
+    lib.fr_occ_frontiers.argtypes = [occp, _f32p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.fr_occ_erode.restype = ctypes.c_int
+    lib.fr_occ_erode.argtypes = [occp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.fr_occ_cells_of.restype = ctypes.c_int
+    lib.fr_occ_cells_of.argtypes = [occp, _f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     _lib = lib
     return lib
 

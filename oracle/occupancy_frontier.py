@@ -12,8 +12,12 @@ Restated from (paths relative to /root/reference):
   planning/astar.py:540-683   build_frontiers               (dilate - free AND unknown, dilate, components, min area 10,
                               "combined" score count / (mean distance + 20))
   datasets/util/map_utils.py:106-125  discretize_coords
-cv2 (absent in this image) is replaced by scipy.ndimage with 8-connectivity (cv2's default) and a NumPy Bresenham;
-torch.unique(dim=0, return_counts=True) by np.unique.  No golden vectors exist for this code in the reference; parity unpinned.
+cv2 (absent in this image) is replaced by scipy.ndimage with 8-connectivity (cv2's default), cv2's border rule for the
+morphology (cells outside the image never constrain), and OpenCV's 8-connected LineIterator as cv::line drives it
+(opencv/modules/imgproc/src/drawing.cpp, 4.x: left-to-right, count = major + 1, err = major - 2 minor), restated from the
+published algorithm; torch.unique(dim=0, return_counts=True) by np.unique.  float32 throughout, `c2w @ pts` accumulated left
+to right.  No golden vectors exist for this code in the reference and cv2 cannot be run here: parity unpinned.
+This module is also the checker of the GPU kernels in fisher-nerf-customized_amd/csrc/fisher_occ.hip (tests only).
 """
 import numpy as np
 from scipy import ndimage
@@ -22,31 +26,57 @@ _EIGHT = np.ones((3, 3), dtype=bool)
 
 
 def discretize_coords(x, z, grid_dim, cell_size, map_center):
-    xb = np.floor((x - map_center[0]) / cell_size) + (grid_dim[0] - 1) / 2.0
-    zb = np.floor((z - map_center[1]) / cell_size) + (grid_dim[1] - 1) / 2.0
+    x, z = np.asarray(x, dtype=np.float32), np.asarray(z, dtype=np.float32)
+    cx, cz, cell = np.float32(map_center[0]), np.float32(map_center[1]), np.float32(cell_size)
+    xb = np.floor((x - cx) / cell) + np.float32((grid_dim[0] - 1) / 2.0)
+    zb = np.floor((z - cz) / cell) + np.float32((grid_dim[1] - 1) / 2.0)
     xb = np.clip(xb.astype(np.int32), 0, grid_dim[0] - 1)
     zb = np.clip(zb.astype(np.int32), 0, grid_dim[1] - 1)
     return np.stack([xb, zb], axis=1).astype(np.int64)
 
 
 def _line(canvas, x0, y0, x1, y1):
-    """Bresenham, 1-pixel wide (cv2.line(..., color=1, thickness=1))."""
-    dx, dy = abs(x1 - x0), -abs(y1 - y0)
-    sx, sy = (1 if x0 < x1 else -1), (1 if y0 < y1 else -1)
-    err = dx + dy
+    """cv2.line(canvas, (x0, y0), (x1, y1), 1, 1): OpenCV's 8-connected LineIterator, left to right."""
+    if x1 < x0:
+        x0, y0, x1, y1 = x1, y1, x0, y0
+    dx, dy = x1 - x0, y1 - y0
+    sy = -1 if dy < 0 else 1
+    dy = abs(dy)
+    steep = dy > dx
+    major, minor = (dy, dx) if steep else (dx, dy)
+    err = major - 2 * minor
     h, w = canvas.shape
-    while True:
-        if 0 <= y0 < h and 0 <= x0 < w:
-            canvas[y0, x0] = 1
-        if x0 == x1 and y0 == y1:
-            break
-        e2 = 2 * err
-        if e2 >= dy:
-            err += dy
-            x0 += sx
-        if e2 <= dx:
-            err += dx
-            y0 += sy
+    x, y = x0, y0
+    for _ in range(major + 1):
+        if 0 <= y < h and 0 <= x < w:
+            canvas[y, x] = 1
+        both = err < 0
+        err += -2 * minor + (2 * major if both else 0)
+        if steep:
+            y += sy
+            x += 1 if both else 0
+        else:
+            x += 1
+            y += sy if both else 0
+
+
+def sample_fractions():
+    """astar.py:236-238: torch.linspace(1e-3, 0.95, 11) clamped at 0, last entry set to 1 (the depth point itself)."""
+    import torch
+    f = torch.linspace(1e-3, 0.95, 11).clamp_(min=0.).numpy().astype(np.float32)
+    f[-1] = 1.0
+    return f
+
+
+def _to_world(c2w, x, y, z):
+    """c2w @ (x, y, z, 1) in float32, accumulated left to right."""
+    c = c2w.astype(np.float32)
+    return tuple(((c[r, 0] * x + c[r, 1] * y) + c[r, 2] * z) + c[r, 3] for r in range(3))
+
+
+def _open3(a):
+    er = ndimage.binary_erosion(a, structure=_EIGHT, border_value=1)
+    return ndimage.binary_dilation(er, structure=_EIGHT, border_value=0)
 
 
 class OccupancyMap:
@@ -75,31 +105,29 @@ class OccupancyMap:
         CX, CY, FX, FY = self.K[0, 2], self.K[1, 2], self.K[0, 0], self.K[1, 1]
         xg, yg = np.meshgrid(np.arange(0, width, downsample, dtype=np.float32), np.arange(0, height, downsample, dtype=np.float32))
         xx, yy = ((xg - CX) / FX)[None], ((yg - CY) / FY)[None]
-        sampled_z = np.linspace(1e-3, 0.95, 11, dtype=np.float32).reshape(-1, 1, 1) * np.ones((1, xx.shape[1], xx.shape[2]), np.float32)
-        sampled_z = np.clip(sampled_z, 0.0, None)
-        sampled_z[-1, 0, 0] = 1.0
+        sampled_z = sample_fractions().reshape(-1, 1, 1)               # (K, 1, 1): the last sample is the depth point, every pixel
         depth_z = sampled_z * depth[:, ::downsample, ::downsample]
         mask = (depth_z > 0) & (depth_z < self.pcd_far_distance)
-        pts = np.stack((xx * depth_z, yy * depth_z, depth_z, np.ones_like(depth_z)), axis=0)      # 4 x K x H x W
-        free_particles = pts[:, :-1].reshape(4, -1)[:, mask[:-1].reshape(-1)]
-        depth_pts = pts[:, -1].reshape(4, -1)[:, mask[-1].reshape(-1)]
+        px, py = xx * depth_z, yy * depth_z
         grid = np.zeros((3, self.grid_dim[1], self.grid_dim[0]), dtype=np.float32)
         occ_map = np.zeros_like(self.occ_map)
 
-        free_particles = c2w @ free_particles
-        mc = discretize_coords(free_particles[0], free_particles[2], self.grid_dim, self.cell_size, self.map_center)
-        valid = (free_particles[1] >= self.height_lower) & (free_particles[1] <= self.height_upper)
+        m = mask[:-1].reshape(-1)
+        wx, wy, wz = _to_world(c2w, px[:-1].reshape(-1)[m], py[:-1].reshape(-1)[m], depth_z[:-1].reshape(-1)[m])
+        mc = discretize_coords(wx, wz, self.grid_dim, self.cell_size, self.map_center)
+        valid = (wy >= np.float32(self.height_lower)) & (wy <= np.float32(self.height_upper))
         uv, counts = np.unique(mc[valid], axis=0, return_counts=True)
-        grid[2, uv[:, 1], uv[:, 0]] = counts + 1e-5
-        occ_map += 0.01 * grid
+        grid[2, uv[:, 1], uv[:, 0]] = counts.astype(np.float32) + np.float32(1e-5)
+        occ_map += np.float32(0.01) * grid
 
         grid[:] = 0.0
-        depth_pts = c2w @ depth_pts
-        valid = (depth_pts[1] >= self.height_lower) & (depth_pts[1] <= self.height_upper)
-        mc = discretize_coords(depth_pts[0], depth_pts[2], self.grid_dim, self.cell_size, self.map_center)
+        m = mask[-1].reshape(-1)
+        wx, wy, wz = _to_world(c2w, px[-1].reshape(-1)[m], py[-1].reshape(-1)[m], depth_z[-1].reshape(-1)[m])
+        valid = (wy >= np.float32(self.height_lower)) & (wy <= np.float32(self.height_upper))
+        mc = discretize_coords(wx, wz, self.grid_dim, self.cell_size, self.map_center)
         uv, counts = np.unique(mc[valid], axis=0, return_counts=True)
-        grid[1, uv[:, 1], uv[:, 0]] = counts + 1e-5
-        grid[1] *= 100
+        grid[1, uv[:, 1], uv[:, 0]] = counts.astype(np.float32) + np.float32(1e-5)
+        grid[1] *= np.float32(100)
         occ_map += grid
 
         line_canvas = np.zeros((self.grid_dim[1], self.grid_dim[0]), dtype=np.uint8)
@@ -107,7 +135,7 @@ class OccupancyMap:
             _line(line_canvas, int(x), int(z), cam_pos_x, cam_pos_z)
         fz, fx = np.where(line_canvas > 0)
         occ_map[2, fz, fx] = 1.0
-        self.occ_map += occ_map / (occ_map.sum(axis=0, keepdims=True) + 1e-5)
+        self.occ_map += occ_map / (((occ_map[0] + occ_map[1]) + occ_map[2])[None] + np.float32(1e-5))
 
     # planning/astar.py:401-447
     def build_connected_freespace(self, gaussian_points=None):
@@ -120,7 +148,7 @@ class OccupancyMap:
             uv, counts = np.unique(mc, axis=0, return_counts=True)
             uv = uv[counts > 25]
             free_space[uv[:, 1], uv[:, 0]] = 0
-        free_space = ndimage.binary_opening(free_space, structure=_EIGHT)
+        free_space = _open3(free_space)
         labels, n = ndimage.label(free_space, structure=_EIGHT)
         if n == 0:
             return np.zeros_like(free_space, dtype=np.uint8)
@@ -128,32 +156,53 @@ class OccupancyMap:
         sizes[0] = 0
         return (labels == sizes.argmax()).astype(np.uint8)
 
-    # planning/astar.py:540-683 ("combined" selection)
-    def build_frontiers(self, gaussian_points=None):
+    # planning/astar.py:540-683
+    def build_frontiers(self, gaussian_points=None, method="combined", min_area=10, details=None):
         free_space = self.build_connected_freespace(gaussian_points)
         unknown = (self.occ_map.argmax(axis=0) == 0)
         dil = ndimage.binary_dilation(free_space.astype(bool), structure=_EIGHT)
         boundary = dil.astype(np.uint8) - free_space
         frontier = (boundary.astype(bool) & unknown)
+        if details is not None:
+            details["frontier"] = frontier.astype(np.uint8)
         if frontier.sum() == 0:
             return None, free_space
         frontier = ndimage.binary_dilation(frontier, structure=_EIGHT)
         labels, n = ndimage.label(frontier, structure=_EIGHT)
         counts = np.bincount(labels.ravel())[1:]
-        lab = np.arange(1, n + 1)[counts > 10]
-        counts = counts[counts > 10]
+        lab = np.arange(1, n + 1)[counts > min_area]
+        counts = counts[counts > min_area]
+        if details is not None:
+            details["components"] = int(len(lab))
         if len(lab) == 0:
             return None, free_space
-        best, best_score = -1, 0.0
-        for l, c in zip(lab, counts):
-            pos = np.stack(np.where(labels == l), axis=1)
-            if len(pos) < 4:
-                continue
-            score = c / (np.linalg.norm(pos - self.cam_pos, axis=1).mean() + 20)
-            if score > best_score:
-                best, best_score = l, score
+        best = -1
+        if method == "largest":
+            best = lab[np.argsort(counts, kind="stable")[::-1][0]]
+        elif method == "combined":
+            best_score = 0.0
+            for l, c in zip(lab, counts):
+                pos = np.stack(np.where(labels == l), axis=1)
+                if len(pos) < 4:
+                    continue
+                score = c / (np.linalg.norm(pos - self.cam_pos, axis=1).mean() + 20)
+                if score > best_score:
+                    best, best_score = l, score
+        elif method == "closest":
+            best_d = 1e4
+            for l in lab:
+                pos = np.stack(np.where(labels == l), axis=1)
+                if len(pos) < 4:
+                    continue
+                d = np.linalg.norm(pos - self.cam_pos, axis=1).mean()
+                if d < best_d:
+                    best, best_d = l, d
+        else:
+            raise ValueError(method)
         if best == -1:
             return None, free_space
+        if details is not None:
+            details["target"] = (labels == best).astype(np.uint8)
         px = np.stack(np.where(labels == best), axis=1)[:, [1, 0]]
         pts = (px - np.array([[self.grid_dim[0] // 2, self.grid_dim[1] // 2]])) * self.cell_size + self.map_center[None]
         return pts, free_space

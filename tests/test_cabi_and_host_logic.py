@@ -20,9 +20,12 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "fisher_rast.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr))
+    declared = set()
+    for h in ("fisher_rast.h", "fisher_occ.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared |= set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr))
+    assert {"fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of", "fr_occ_workspace_bytes"} <= declared
     assert {"fr_forward", "fr_backward", "fr_fisher_views", "fr_mark_visible", "fr_knn_dist2", "fr_version",
             "fr_last_error", "fr_workspace_bytes", "fr_workspace_layout", "fr_fisher_workspace_bytes",
             "fr_knn_workspace_bytes"} <= declared
@@ -49,6 +52,20 @@ def test_workspace_queries_are_host_only(lib):
     assert int(lib.fr_fisher_workspace_bytes(500000, 256, 256, 64, 64 * 500000, 11)) > n
     assert int(lib.fr_fisher_workspace_bytes(10, 0, 256, 1, 1, 4)) == 0 and int(lib.fr_fisher_workspace_bytes(10, 16, 16, 1, 1, 5)) == 0
     assert int(lib.fr_knn_workspace_bytes(1000)) >= 1000 * 20
+
+
+def test_occupancy_queries_and_validation_without_gpu(lib):
+    from fisher_rast._lib import OccCfg
+    cfg = OccCfg(768, 768, 0.05, 0.0, 0.0, -0.6, 0.6, 10.0)
+    n = int(lib.fr_occ_workspace_bytes(ctypes.byref(cfg)))
+    assert n >= 768 * 768 * (8 + 1 + 1 + 1 + 1 + 4 + 4 + 8)
+    bad = OccCfg(768, -1, 0.05, 0.0, 0.0, -0.6, 0.6, 10.0)
+    assert int(lib.fr_occ_workspace_bytes(ctypes.byref(bad))) == 0
+    assert lib.fr_occ_update(ctypes.byref(cfg), None, 64, 64, 1, None, None, None, 11, 0, 0, None, None, 0, None) == 1
+    assert b"fr_occ_update" in lib.fr_last_error()
+    assert lib.fr_occ_freespace(ctypes.byref(cfg), 8, None, 0, 8, None, 0, None) == 3            # FR_ENOSPACE
+    assert lib.fr_occ_frontiers(ctypes.byref(cfg), 8, 8, 0, 0, 7, 10, 8, 8, 8, 0, 8, None, 0, None) == 1
+    assert lib.fr_occ_cells_of(ctypes.byref(cfg), None, 0, None, None) == 0                       # empty input is fine
 
 
 def test_argument_validation_without_gpu(lib):
