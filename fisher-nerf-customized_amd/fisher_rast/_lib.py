@@ -100,6 +100,9 @@ def load():
             f"{SO_PATH} is missing: the HIP extension has not been built "
             "(run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root). "
             "There is no CPU fallback for this path.")
+    # PyTorch-ROCm ships its own HIP runtime; it has to be the one already in the process when this library's
+    # libamdhip64 dependency is resolved, or the two would each hold their own (device-less) state.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(SO_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):
