@@ -1614,6 +1614,7 @@ struct FrBwdArgs {
 	int u_only;                  // 1: accumulate only (mean2D, conic, colour, opacity) -- the other leaves come from k_backward_finish
 	float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolors; float* dL_dmean3D;
 	float* dL_dcov3D; float* dL_dscale; float* dL_drot;
+	const float* dL_dmean2D_b;   // or null: screen-space gradient of a second feature image (fr_backward_pair), added in k_backward_finish
 };
 
 __device__ __forceinline__ float fr_powi(float x, int power)
@@ -2030,8 +2031,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_finish(FrParams p, FrBw
 	float c3[6];
 #pragma unroll
 	for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
-	const float u[5] = { b.dL_dmean2D[3 * (size_t)i], b.dL_dmean2D[3 * (size_t)i + 1], b.dL_dconic[4 * (size_t)i],
-	                     b.dL_dconic[4 * (size_t)i + 1], b.dL_dconic[4 * (size_t)i + 3] };
+	float u[5] = { b.dL_dmean2D[3 * (size_t)i], b.dL_dmean2D[3 * (size_t)i + 1], b.dL_dconic[4 * (size_t)i],
+	               b.dL_dconic[4 * (size_t)i + 1], b.dL_dconic[4 * (size_t)i + 3] };
+	if (b.dL_dmean2D_b) { u[0] += b.dL_dmean2D_b[3 * (size_t)i]; u[1] += b.dL_dmean2D_b[3 * (size_t)i + 1]; }
 	float A[3][5];
 	float B[6][3];
 	fr_mean_jacobian(po, c3, vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, B);
@@ -2400,6 +2402,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	dim3 grid(p.T, 1), block(FR_THREADS);
 	b.only_flagged = nullptr;
 	b.u_only = 0;
+	b.dL_dmean2D_b = nullptr;
 	if (power == 1)
 	{
 		// gradients: sum u per splat in the tile kernel, Jacobian chain once per Gaussian; tiles that do not fit the LDS
@@ -2435,6 +2438,99 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 }
 
 // ---- fused Fisher scorer ---------------------------------------------------------------------------------
+// ---- a second feature image on the geometry fr_forward binned (models/SLAM/gaussian.py:203-211) -------------------
+extern "C" int fr_forward_features(const fr_raster_cfg* cfg, const float* features,
+                                   const void* geom_ws, const void* binning_ws, void* image_ws,
+                                   float* out_features, fr_stream_t stream)
+{
+	if (!cfg || cfg->P < 0 || cfg->image_width <= 0 || cfg->image_height <= 0) return fr_fail(FR_EINVAL, "fr_forward_features: bad cfg");
+	hipStream_t s = (hipStream_t)stream;
+	const int P = cfg->P, W = cfg->image_width, H = cfg->image_height;
+	if (!out_features) return fr_fail(FR_EINVAL, "fr_forward_features: null output");
+	if (P == 0)
+	{
+		(void)hipMemsetAsync(out_features, 0, (size_t)3 * W * H * 4, s);
+		return FR_OK;
+	}
+	if (!features || !geom_ws || !binning_ws || !image_ws || !cfg->bg) return fr_fail(FR_EINVAL, "fr_forward_features: null pointer");
+	FrLayout L = fr_layout(P, W, H, 1, 1);
+	fr_gaussians g0;
+	memset(&g0, 0, sizeof(g0));
+	FrParams p;
+	fr_fill_params(p, cfg, &g0, 1);
+	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
+	hipLaunchKernelGGL(k_render_forward, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
+	                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr);
+	return fr_check_launch("k_render_forward(features)");
+}
+
+extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                                const void* geom_ws, const void* binning_ws, const void* image_ws,
+                                const float* dL_dout_color, const float* features, const float* dL_dout_features,
+                                float* dL_dmeans2D, float* dL_dmeans2D_features, float* dL_dcolors, float* dL_dfeatures,
+                                float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                                float* dL_drotations, float* dL_dconic, fr_stream_t stream)
+{
+	int rc = fr_validate(cfg, g, "fr_backward_pair", false);
+	if (rc) return rc;
+	hipStream_t s = (hipStream_t)stream;
+	const int P = cfg->P, W = cfg->image_width, H = cfg->image_height;
+	if (P == 0) return FR_OK;
+	if (!g->colors_precomp || g->shs) return fr_fail(FR_EINVAL, "fr_backward_pair: needs colors_precomp (no SH)");
+	if (!geom_ws || !binning_ws || !image_ws || !radii || !dL_dout_color || !features || !dL_dout_features || !dL_dmeans2D ||
+	    !dL_dmeans2D_features || !dL_dcolors || !dL_dfeatures || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
+	    !dL_drotations || !dL_dconic)
+		return fr_fail(FR_EINVAL, "fr_backward_pair: null pointer");
+	(void)hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dmeans2D_features, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dfeatures, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s);
+	(void)hipMemsetAsync(dL_dmeans3D, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_dcov3D, 0, (size_t)P * 6 * 4, s);
+	(void)hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * 4, s);
+	(void)hipMemsetAsync(dL_drotations, 0, (size_t)P * 4 * 4, s);
+	(void)hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * 4, s);
+	FrLayout L = fr_layout(P, W, H, 1, 1);
+	FrParams p;
+	fr_fill_params(p, cfg, g, 1);
+	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
+	p.radii = (int*)radii;
+	p.cov3D = g->cov3D_precomp ? g->cov3D_precomp : p.cov3D_out;
+	const bool sr = g->scales != nullptr;
+	dim3 grid(p.T, 1), block(FR_THREADS);
+	uint8_t* fallback = (uint8_t*)p.tile_fill;
+	FrBwdArgs b;
+	b.final_T = (const float*)((const char*)image_ws + L.final_T);
+	b.n_contrib = (const uint32_t*)((const char*)image_ws + L.n_contrib);
+	b.power = 1;
+	b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity;
+	b.dL_dmean3D = dL_dmeans3D; b.dL_dcov3D = dL_dcov3D; b.dL_dscale = dL_dscales; b.dL_drot = dL_drotations;
+	b.dL_dmean2D_b = nullptr;
+	// one tile pass per image: both add into dL_dconic / dL_dopacity, each keeps its own screen-space and colour gradients
+	for (int pass = 0; pass < 2; pass++)
+	{
+		b.dL_dpix = pass ? dL_dout_features : dL_dout_color;
+		b.colors = pass ? features : g->colors_precomp;
+		b.dL_dmean2D = pass ? dL_dmeans2D_features : dL_dmeans2D;
+		b.dL_dcolors = pass ? dL_dfeatures : dL_dcolors;
+		b.only_flagged = nullptr; b.u_only = 0;
+		hipLaunchKernelGGL(k_backward_lin_tile, dim3(p.T), block, 0, s, p, b, fallback);
+		if ((rc = fr_check_launch("k_backward_lin_tile"))) return rc;
+		b.only_flagged = fallback; b.u_only = 1;
+		if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
+		else hipLaunchKernelGGL((k_backward_tile<false, false>), grid, block, 0, s, p, b);
+		if ((rc = fr_check_launch("k_backward_tile(flagged)"))) return rc;
+	}
+	// Jacobian chain once per Gaussian on the summed screen-space gradients
+	b.dL_dmean2D = dL_dmeans2D; b.dL_dmean2D_b = dL_dmeans2D_features;
+	b.dL_dcolors = dL_dcolors; b.colors = g->colors_precomp;
+	dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
+	if (sr) hipLaunchKernelGGL((k_backward_finish<true, false>), gp, block, 0, s, p, b, (float*)nullptr);
+	else hipLaunchKernelGGL((k_backward_finish<false, false>), gp, block, 0, s, p, b, (float*)nullptr);
+	return fr_check_launch("k_backward_finish");
+}
+
 struct FrFisherLayout {
 	size_t radii, vis_n, splat, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };

@@ -22,3 +22,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 def mark_visible(means3D, viewmatrix, projmatrix):
     return _ops.mark_visible(means3D, viewmatrix, projmatrix)
+
+
+# ---- not in the reference's pybind module: the second feature image on shared geometry (include/fisher_rast.h) ----
+def rasterize_features(features, raster_cfg_args, geomBuffer, binningBuffer, imageBuffer):
+    return _ops.rasterize_forward_features(features, raster_cfg_args, geomBuffer, binningBuffer, imageBuffer)
+
+
+def rasterize_gaussians_backward_pair(background, means3D, radii, colors, features, scales, rotations, scale_modifier,
+                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                      dL_dout_features, campos, geomBuffer, binningBuffer, imageBuffer):
+    return _ops.rasterize_backward_pair(background, means3D, radii, colors, features, scales, rotations, scale_modifier,
+                                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                        dL_dout_features, campos, geomBuffer, binningBuffer, imageBuffer)

@@ -70,6 +70,46 @@ class _RasterizeGaussians(torch.autograd.Function):
                 None, None)
 
 
+class _RasterizeGaussiansPair(torch.autograd.Function):
+    """Colour image + a second feature image (the reference's depth / silhouette render, gaussian.py:203-211) on ONE
+    projection, binning and sort.  Inputs (means3D, means2D, means2D_features, colors_precomp, features, opacities, scales,
+    rotations, cov3Ds_precomp, raster_settings); `means2D` receives the colour image's screen-space gradient only, as
+    in the reference where each render has its own `means2D` and the densifier reads the colour render's."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, means2D_features, colors_precomp, features, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        empty = torch.Tensor([])
+        num_rendered, color, radii, geom, binning, img, depth = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, empty,
+            rs.sh_degree, rs.campos, rs.prefiltered)
+        feat_img = _C.rasterize_features(features, (int(means3D.shape[0]), rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy,
+                                                    rs.scale_modifier, rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos),
+                                         geom, binning, img)
+        ctx.raster_settings = rs
+        ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth, feat_img
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, _grad_depth, grad_features):
+        rs = ctx.raster_settings
+        colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
+        if grad_features is None:
+            grad_features = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
+        (g_m2, g_m2f, g_col, g_feat, g_op, g_m3, g_cov, g_sc, g_rot) = _C.rasterize_gaussians_backward_pair(
+            rs.bg, means3D, radii, colors_precomp, features, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_features, rs.campos, geom, binning, img)
+
+        def fit(g, like):
+            return None if (like is None or like.numel() == 0) else g
+        return (g_m3, g_m2, g_m2f, g_col, g_feat, g_op, fit(g_sc, scales), fit(g_rot, rotations), fit(g_cov, cov3Ds_precomp), None)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, backward_power):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -102,3 +142,21 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings, self.backward_power)
+
+    def forward_pair(self, means3D, means2D, opacities, colors_precomp, features, scales=None, rotations=None,
+                     cov3D_precomp=None, means2D_features=None):
+        """Not in the reference: `(color, radii, depth, feature_image)` -- what two calls with `colors_precomp` and then
+        `features` (same geometry) return, from one projection / binning / sort, with one fused backward (power 1)."""
+        if self.backward_power != 1:
+            raise Exception('forward_pair is the training-step path: backward_power must be 1')
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        if means2D_features is None:
+            means2D_features = torch.zeros_like(means2D)
+        return _RasterizeGaussiansPair.apply(means3D, means2D, means2D_features, colors_precomp, features, opacities, scales,
+                                             rotations, cov3D_precomp, self.raster_settings)

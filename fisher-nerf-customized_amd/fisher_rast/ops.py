@@ -175,6 +175,52 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
+def rasterize_forward_features(features, raster_cfg_args, geomBuffer, binningBuffer, imageBuffer):
+    """A second [P,3] feature array composited over the geometry the last `rasterize_forward` binned
+    (fr_forward_features): returns the [3,H,W] image.  raster_cfg_args = (P, H, W, tanfovx, tanfovy, scale_modifier, bg, view, proj, campos)."""
+    P, H, W, tfx, tfy, mod, bg, view, proj, cpos = raster_cfg_args
+    dev = geomBuffer.device if P else bg.device
+    out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    feats = _prep(features, dev)
+    bg, view, proj, cpos = _prep(bg, dev), _prep(view, dev), _prep(proj, dev), _prep(cpos, dev)
+    cfg = _raster_cfg(P, H, W, tfx, tfy, mod, 0, 0, False, bg, view, proj, cpos)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().fr_forward_features(ctypes.byref(cfg), _ptr(feats), geomBuffer.data_ptr() if P else None,
+                                                   binningBuffer.data_ptr() if P else None, imageBuffer.data_ptr() if P else None,
+                                                   _ptr(out), _stream(dev)), "fr_forward_features")
+    return out
+
+
+def rasterize_backward_pair(background, means3D, radii, colors, features, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_features, campos,
+                            geomBuffer, binningBuffer, imageBuffer):
+    """Backward of (colour image, feature image) on shared geometry, grad_power 1 (fr_backward_pair): returns
+    (dL_dmeans2D [colour image only], dL_dmeans2D_features, dL_dcolors, dL_dfeatures, dL_dopacity, dL_dmeans3D, dL_dcov3D,
+     dL_dscales, dL_drotations)."""
+    _need_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    means3D, colors, feats = _prep(means3D, dev), _prep(colors, dev), _prep(features, dev)
+    scales, rotations, cov3D_precomp = _prep(scales, dev), _prep(rotations, dev), _prep(cov3D_precomp, dev)
+    bg, view, proj, cpos = _prep(background, dev), _prep(viewmatrix, dev), _prep(projmatrix, dev), _prep(campos, dev)
+    dL, dLf = _prep(dL_dout_color, dev), _prep(dL_dout_features, dev)
+
+    def new(*shape):
+        return torch.zeros(shape, dtype=torch.float32, device=dev)
+    m2, m2f, dc, df = new(P, 3), new(P, 3), new(P, 3), new(P, 3)
+    dop, dm3, dcov, dsc, drot, dcon = new(P, 1), new(P, 3), new(P, 6), new(P, 3), new(P, 4), new(P, 2, 2)
+    if P != 0:
+        cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, 0, 0, False, bg, view, proj, cpos)
+        g = _gaussians(means3D, colors, None, None, scales, rotations, cov3D_precomp)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().fr_backward_pair(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
+                                                    binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), _ptr(feats), _ptr(dLf),
+                                                    _ptr(m2), _ptr(m2f), _ptr(dc), _ptr(df), _ptr(dop), _ptr(dm3), _ptr(dcov),
+                                                    _ptr(dsc), _ptr(drot), _ptr(dcon), _stream(dev)), "fr_backward_pair")
+    return m2, m2f, dc, df, dop, dm3, dcov, dsc, drot
+
+
 class FisherScorer:
     """Batched Fisher-information scorer for one Gaussian map and one camera.
 

@@ -18,6 +18,7 @@
  *                           -> Rasterizer::forward         RAST/cuda_rasterizer/rasterizer_impl.cu:198-339
  *   fr_backward          <- RasterizeGaussiansBackwardCUDA RAST/rasterize_points.cu:117-196
  *                           -> Rasterizer::backward        RAST/cuda_rasterizer/rasterizer_impl.cu:343-434
+ *   fr_forward_features, fr_backward_pair <- the second Renderer call of get_loss, models/SLAM/gaussian.py:203-211
  *   fr_fisher_views      <- the Python loop GaussianSLAM.pose_eval / compute_H_train / compute_Hessian
  *                           models/SLAM/gaussian.py:1338-1375, 1503-1570 and
  *                           models/SLAM/gaussian_object.py:1541-1551, 1591-1617, 1940-2045
@@ -119,6 +120,25 @@ int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* 
                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
                 fr_stream_t stream);
+
+/* ---- second feature image on the same geometry (training step) ------------------------
+ * The reference's get_loss renders twice with identical means / scales / rotations / opacities / camera and different
+ * colours: RGB, then (depth, 1, depth^2) for depth + silhouette (models/SLAM/gaussian.py:199-211,
+ * slam_helpers.py:268-279) -- two full rasteriser forwards and two full backwards.
+ * fr_forward_features composites another [P,3] feature array over what fr_forward just projected, binned and sorted
+ * (same cfg and workspaces; no preprocess, no sort).  fr_backward_pair is the backward of both images in one call
+ * (grad_power 1): one tile pass per image, the per-Gaussian Jacobian chain once.  dL_dmeans2D receives the colour image's
+ * screen-space gradient only -- the statistic the densifier reads (gaussian.py:207) -- dL_dmeans2D_features the other
+ * image's; every other output is the sum over both images, except dL_dcolors / dL_dfeatures. */
+int fr_forward_features(const fr_raster_cfg* cfg, const float* features,
+                        const void* geom_ws, const void* binning_ws, void* image_ws,
+                        float* out_features, fr_stream_t stream);
+int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                     const void* geom_ws, const void* binning_ws, const void* image_ws,
+                     const float* dL_dout_color, const float* features, const float* dL_dout_features,
+                     float* dL_dmeans2D, float* dL_dmeans2D_features, float* dL_dcolors, float* dL_dfeatures,
+                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                     float* dL_drotations, float* dL_dconic, fr_stream_t stream);
 
 /* ---- fused multi-view Fisher scorer -------------------------------------------------------------- */
 

@@ -227,3 +227,56 @@ def test_autograd_front_end_with_shs(gpu):
     assert shs.grad.shape == (P, 4, 3) and float(shs.grad.abs().sum()) > 0
     assert t["means3D"].grad.shape == (P, 3) and m2d.grad.shape == (P, 3)
     assert torch.isfinite(t["scales"].grad).all() and torch.isfinite(t["rotations"].grad).all()
+
+
+def test_fused_rgb_depth_silhouette_pair(gpu, oracle):
+    """forward_pair / fr_forward_features / fr_backward_pair: the double render of the reference's get_loss
+    (models/SLAM/gaussian.py:199-211) on one projection, binning and sort.  Forward images bit-identical to two separate
+    calls; every leaf gradient equal to the sum of the two separate backwards; `means2D.grad` = the colour render's only."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from fisher_rast import synthetic
+    from models.SLAM.utils.recon_helpers import setup_camera
+    from models.SLAM.utils.slam_helpers import (transformed_params2rendervar, transformed_params2depthplussilhouette,
+                                                 render_rgb_depth_sil)
+    P, W, H = 6000, 160, 112
+    raw = synthetic.room_shell(P, 21)
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(1, 22))[0].to(gpu)
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    g = torch.Generator().manual_seed(23)
+    w_im, w_ds = torch.randn((3, H, W), generator=g).to(gpu), torch.randn((3, H, W), generator=g).to(gpu)
+    names = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
+
+    def leaves():
+        return {k: raw[k].clone().to(gpu).requires_grad_(True) for k in names}
+
+    def frame_pts(params):
+        pts = params["means3D"]
+        return (w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3]
+
+    # reference flow: two renders
+    pa = leaves()
+    tp = frame_pts(pa)
+    rv = transformed_params2rendervar(pa, tp)
+    dv = transformed_params2depthplussilhouette(pa, w2c, tp)
+    rv["means2D"].retain_grad()
+    im_a, rad_a, _ = Renderer(raster_settings=cam)(**rv)
+    ds_a, _, _ = Renderer(raster_settings=cam)(**dv)
+    ((im_a * w_im).sum() + (ds_a * w_ds).sum()).backward()
+    # fused flow
+    pb = leaves()
+    im_b, rad_b, ds_b, rvb = render_rgb_depth_sil(pb, cam, w2c, frame_pts(pb))
+    ((im_b * w_im).sum() + (ds_b * w_ds).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(im_a, im_b) and torch.equal(ds_a, ds_b) and torch.equal(rad_a, rad_b)
+    assert int((rad_a > 0).sum()) > 500
+    for k in names:
+        assert_close(pb[k].grad.cpu().numpy(), pa[k].grad.cpu().numpy(), 1e-4, f"fused pair d/d{k}", atol_frac=1e-6)
+    assert_close(rvb["means2D"].grad.cpu().numpy(), rv["means2D"].grad.cpu().numpy(), 1e-5, "means2D.grad (colour render only)", atol_frac=1e-7)
+    # and the depth / silhouette image against the oracle
+    n = {k: v.detach().cpu().numpy() for k, v in dv.items() if k != "means2D"}
+    ocam = oracle.setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4))
+    fw = oracle.rasterize_forward(ocam, n["means3D"], n["opacities"], colors_precomp=n["colors_precomp"], scales=n["scales"], rotations=n["rotations"])
+    assert np.array_equal(ds_b.detach().cpu().numpy(), fw["color"])
+    with pytest.raises(Exception):
+        Renderer(raster_settings=cam, backward_power=2).forward_pair(rv["means3D"], rv["means2D"], rv["opacities"], rv["colors_precomp"],
+                                                                    dv["colors_precomp"], scales=rv["scales"], rotations=rv["rotations"])

@@ -37,3 +37,36 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"config4: P={P} {W}x{H} tile instances {R}  forward+backward(power=1): {dt*1e3:.2f} ms/step; |dL_dmeans3D| = {float(grads[3].abs().sum()):.4e}")
+
+# ---- the double render of the reference's get_loss (RGB, then depth / silhouette / depth^2) vs the fused pair -------------
+z = tp[:, 2:3]
+feats = torch.cat((z, torch.ones_like(z), z * z), 1).contiguous()
+dL2 = torch.randn((3, H, W), generator=g).to(dev)
+cfg_args = (P, H, W, cam.tanfovx, cam.tanfovy, 1.0, cam.bg, cam.viewmatrix, cam.projmatrix, cam.campos)
+
+
+def two_renders():
+    out = []
+    for col, d in ((act["rgb_colors"], dL), (feats, dL2)):
+        R, color, radii, geom, binning, img, depth = ops.rasterize_forward(cam.bg, tp, col, act["opacities"], act["scales"], act["rotations"], 1.0, e,
+                                                                       cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, cam.campos, False)
+        out.append(ops.rasterize_backward(cam.bg, tp, radii, col, act["scales"], act["rotations"], 1.0, e, cam.viewmatrix, cam.projmatrix,
+                                          cam.tanfovx, cam.tanfovy, d, e, 0, cam.campos, geom, R, binning, img, 1))
+    return out
+
+
+def fused_pair():
+    R, color, radii, geom, binning, img, depth = ops.rasterize_forward(cam.bg, tp, act["rgb_colors"], act["opacities"], act["scales"], act["rotations"], 1.0, e,
+                                                                   cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, cam.campos, False)
+    fimg = ops.rasterize_forward_features(feats, cfg_args, geom, binning, img)
+    return ops.rasterize_backward_pair(cam.bg, tp, radii, act["rgb_colors"], feats, act["scales"], act["rotations"], 1.0, e, cam.viewmatrix,
+                                       cam.projmatrix, cam.tanfovx, cam.tanfovy, dL, dL2, cam.campos, geom, binning, img)
+
+
+for name, fn in (("two renders (reference flow)", two_renders), ("fused pair", fused_pair)):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = fn()
+    torch.cuda.synchronize()
+    print(f"config4 get_loss renders, {name}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms/step")
