@@ -616,37 +616,74 @@ __device__ __forceinline__ void fr_tile_of_block(const FrParams& p, uint32_t& ti
 // ---------------------------------------------------------------------------------------------------------
 // Ascending-only bitonic network ("flip" form): works for any n without padding, because a comparator whose
 // upper element lies beyond n would compare against +inf and never swap.
+// Two network stages per pass over the keys: a thread takes the four keys that two consecutive stages connect, runs
+// both compare-exchange layers in registers and writes them back -- half the LDS traffic and half the barriers of the
+// one-stage-per-pass form.  Positions at or beyond n hold a virtual +inf (never stored).
+__device__ __forceinline__ void fr_cx(uint64_t& lo, uint64_t& hi)
+{
+	const uint64_t a = lo, b = hi;
+	const bool sw = a > b;
+	lo = sw ? b : a; hi = sw ? a : b;
+}
+template <typename KeyPtr>
+__device__ __forceinline__ uint64_t fr_ldk(KeyPtr keys, uint32_t i, uint32_t n) { return i < n ? keys[i] : ~0ull; }
+template <typename KeyPtr>
+__device__ __forceinline__ void fr_stk(KeyPtr keys, uint32_t i, uint32_t n, uint64_t v) { if (i < n) keys[i] = v; }
+
 template <typename KeyPtr>
 __device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid, const uint32_t FR_NT = FR_THREADS)
 {
 	uint32_t n_pad = 1;
 	while (n_pad < n) n_pad <<= 1;
-	for (uint32_t k = 2; k <= n_pad; k <<= 1)
+	if (n_pad < 2) return;
+	// k = 2: one stage
+	for (uint32_t t = tid; t < (n_pad >> 1); t += FR_NT)
 	{
-		// flip stage: i <-> i ^ (k-1)
-		for (uint32_t t = tid; t < (n_pad >> 1); t += FR_NT)
+		uint64_t a = fr_ldk(keys, 2 * t, n), b = fr_ldk(keys, 2 * t + 1, n);
+		fr_cx(a, b);
+		fr_stk(keys, 2 * t, n, a); fr_stk(keys, 2 * t + 1, n, b);
+	}
+	__syncthreads();
+	const uint32_t groups = n_pad >> 2;
+	for (uint32_t k = 4, lk = 2; k <= n_pad; k <<= 1, lk++)
+	{
+		// flip stage (i <-> i ^ (k-1)) fused with the j = k/4 stage: a < b = a + k/4 < c = d - k/4 < d = a ^ (k-1)
 		{
-			const uint32_t half = k >> 1;
-			const uint32_t i = ((t / half) * k) + (t % half);
-			const uint32_t l = i ^ (k - 1);
-			if (l < n)
+			const uint32_t q = k >> 2, qm = q - 1u;
+			for (uint32_t g = tid; g < groups; g += FR_NT)
 			{
-				uint64_t a = keys[i], b = keys[l];
-				if (a > b) { keys[i] = b; keys[l] = a; }
+				const uint32_t base = (g >> (lk - 2)) << lk, r = g & qm;
+				const uint32_t ia = base + r, ib = ia + q, id = base + k - 1u - r, ic = id - q;
+				uint64_t a = fr_ldk(keys, ia, n), b = fr_ldk(keys, ib, n), c = fr_ldk(keys, ic, n), d = fr_ldk(keys, id, n);
+				fr_cx(a, d); fr_cx(b, c);
+				fr_cx(a, b); fr_cx(c, d);
+				fr_stk(keys, ia, n, a); fr_stk(keys, ib, n, b); fr_stk(keys, ic, n, c); fr_stk(keys, id, n, d);
 			}
+			__syncthreads();
 		}
-		__syncthreads();
-		for (uint32_t j = k >> 2; j > 0; j >>= 1)
+		// remaining stages j = k/8 ... 1, two at a time: (j, j/2) connect i, i + j/2, i + j, i + 3j/2
+		uint32_t j = k >> 3, lj = lk - 3;
+		for (; j >= 2; j >>= 2, lj -= 2)
+		{
+			const uint32_t h = j >> 1, lh = lj - 1, hm = h - 1u;
+			for (uint32_t g = tid; g < groups; g += FR_NT)
+			{
+				const uint32_t i0 = ((g >> lh) << (lh + 2)) + (g & hm);
+				const uint32_t i1 = i0 + h, i2 = i0 + j, i3 = i2 + h;
+				uint64_t a = fr_ldk(keys, i0, n), b = fr_ldk(keys, i1, n), c = fr_ldk(keys, i2, n), d = fr_ldk(keys, i3, n);
+				fr_cx(a, c); fr_cx(b, d);
+				fr_cx(a, b); fr_cx(c, d);
+				fr_stk(keys, i0, n, a); fr_stk(keys, i1, n, b); fr_stk(keys, i2, n, c); fr_stk(keys, i3, n, d);
+			}
+			__syncthreads();
+		}
+		if (j == 1)
 		{
 			for (uint32_t t = tid; t < (n_pad >> 1); t += FR_NT)
 			{
-				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
-				const uint32_t l = i + j;
-				if (l < n)
-				{
-					uint64_t a = keys[i], b = keys[l];
-					if (a > b) { keys[i] = b; keys[l] = a; }
-				}
+				uint64_t a = fr_ldk(keys, 2 * t, n), b = fr_ldk(keys, 2 * t + 1, n);
+				fr_cx(a, b);
+				fr_stk(keys, 2 * t, n, a); fr_stk(keys, 2 * t + 1, n, b);
 			}
 			__syncthreads();
 		}
