@@ -1241,16 +1241,20 @@ __device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_fl
 // (ds_add_f32), and the lane that owns an entry then issues ONE global atomic per column for the whole wave -- the
 // reference issues one per pixel per column.
 template <int C, bool HAS_HINV, bool HAS_OUTH>
-__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C == 4 ? (HAS_OUTH ? 4 : 5) : 2))) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C == 4 ? (HAS_OUTH ? 4 : 5) : (HAS_OUTH ? 2 : 4)))) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
                                                                uint8_t* __restrict__ fallback)
 {
 	__shared__ float s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];
 	constexpr int PS = FrPackSize<C>::value;
 	// per-entry registers of pass 2: rgb[3], A'[15], (Cm'[21]), k3, [H_inv columns]
-	constexpr int KO = (C == 11) ? 39 : 18;       // offset of k3 = 1/opacity^2 (times H_inv[3] when only the score is wanted)
+	// QFORM (11 columns, score only): the weighted sum of squared leaves is a quadratic form in u',
+	//   sum_c H_inv[c] (M_c . u')^2 = u'^T Q u',  Q = sum_c H_inv[c] M_c^T M_c  (5 x 5 symmetric, 15 numbers),
+	// so the walk fetches rgb[3], Q[15], k3 instead of 51 values per entry, whatever the number of columns.
+	constexpr bool QFORM = (C == 11) && HAS_HINV && !HAS_OUTH;
+	constexpr int KO = QFORM ? 18 : ((C == 11) ? 39 : 18);   // offset of k3 = 1/opacity^2 (times H_inv[3] when only the score is wanted)
 	constexpr int HO = KO + 1;                    // offset of the H_inv columns
 	constexpr bool FOLD3 = HAS_HINV && !HAS_OUTH; // H_inv[3] folded into k3
-	constexpr int NB = HO + (HAS_HINV ? C : 0);
+	constexpr int NB = QFORM ? 19 : HO + (HAS_HINV ? C : 0);
 	__shared__ uint16_t s_wl[4][FR_WCAP];
 	__shared__ float s_red[4];
 	__shared__ int s_ovf;
@@ -1434,13 +1438,15 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 			fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
 			// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
 			// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
+			float Ap[3][5];
 #pragma unroll
 			for (int r = 0; r < 3; r++)
 			{
-				b[3 + r * 5 + 0] = A[r][0] * ddelx_dx; b[3 + r * 5 + 1] = A[r][1] * ddely_dy;
+				Ap[r][0] = A[r][0] * ddelx_dx; Ap[r][1] = A[r][1] * ddely_dy;
 #pragma unroll
-				for (int c = 2; c < 5; c++) b[3 + r * 5 + c] = -0.5f * A[r][c];
+				for (int c = 2; c < 5; c++) Ap[r][c] = -0.5f * A[r][c];
 			}
+			float Cp[(C == 11) ? 7 : 1][3];
 			int go = 12;
 			if constexpr (C == 11)
 			{
@@ -1451,26 +1457,65 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 #pragma unroll
 				for (int r = 0; r < 7; r++)
 #pragma unroll
-					for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = -0.5f * Cm[r][c];
+					for (int c = 0; c < 3; c++) Cp[r][c] = -0.5f * Cm[r][c];
 				go = 19;
 			}
+			float hv[HAS_HINV ? C : 1];
 			if constexpr (HAS_HINV)
 			{
 				if (per_view_hinv)
 				{
 					const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
 #pragma unroll
-					for (int c = 0; c < C; c++) b[HO + c] = hp[c];
+					for (int c = 0; c < C; c++) hv[c] = hp[c];
 				}
 				else
 				{
 #pragma unroll
-					for (int c = 0; c < C; c++) b[HO + c] = gsv[go + c];
+					for (int c = 0; c < C; c++) hv[c] = gsv[go + c];
 				}
 			}
 			(void)go;
-			b[KO] = inv_o * inv_o;                       // dL_dopacity = G dL_dalpha = w / opacity
-			if constexpr (FOLD3) b[KO] *= b[HO + 3];
+			if constexpr (QFORM)
+			{
+				// upper triangle of Q, row-major, off-diagonal entries doubled: u'^T Q u' = sum_{i <= j} Q'[ij] u_i u_j
+				int q = 3;
+#pragma unroll
+				for (int i = 0; i < 5; i++)
+#pragma unroll
+					for (int j = i; j < 5; j++)
+					{
+						float acc = hv[0] * Ap[0][i] * Ap[0][j] + hv[1] * Ap[1][i] * Ap[1][j] + hv[2] * Ap[2][i] * Ap[2][j];
+						if (i >= 2)
+						{
+#pragma unroll
+							for (int r = 0; r < 7; r++) acc += hv[4 + r] * Cp[r][i - 2] * Cp[r][j - 2];
+						}
+						b[q++] = (i == j) ? acc : 2.0f * acc;
+					}
+				b[KO] = inv_o * inv_o * hv[3];
+			}
+			else
+			{
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+#pragma unroll
+					for (int c = 0; c < 5; c++) b[3 + r * 5 + c] = Ap[r][c];
+				if constexpr (C == 11)
+				{
+#pragma unroll
+					for (int r = 0; r < 7; r++)
+#pragma unroll
+						for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cp[r][c];
+				}
+				if constexpr (HAS_HINV)
+				{
+#pragma unroll
+					for (int c = 0; c < C; c++) b[HO + c] = hv[c];
+				}
+				b[KO] = inv_o * inv_o;                       // dL_dopacity = G dL_dalpha = w / opacity
+				if constexpr (FOLD3) b[KO] *= b[HO + 3];
+			}
 		}
 		const float ahcx = -0.5f * acx, ancy = -acy, ahcz = -0.5f * acz;
 		// Candidate mask.  Entry-major first: the lane that owns entry e marks the pixels of this wave's 16x4 strip that
@@ -1559,32 +1604,50 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 				u[0] = hcx * dx + (hcx * dx + ncy * dy);                              // -(cx dx + cy dy)
 				u[1] = 2.0f * (hcz * dy) + ncy * dx;                                  // -(cz dy + cy dx)
 				u[2] = dx * dx; u[3] = dx * dy; u[4] = dy * dy;
-				float leaf2[C];
-#pragma unroll
-				for (int q = 0; q < 3; q++)
+				if constexpr (QFORM)
 				{
-					const float l = r[3 + q * 5 + 0] * u[0] + r[3 + q * 5 + 1] * u[1] + r[3 + q * 5 + 2] * u[2]
-					              + r[3 + q * 5 + 3] * u[3] + r[3 + q * 5 + 4] * u[4];
-					leaf2[q] = l * l;
-				}
-				leaf2[3] = r[KO];
-				if constexpr (C == 11)
-				{
+					float add = r[KO];
+					int q = 3;
 #pragma unroll
-					for (int q = 0; q < 7; q++)
+					for (int i = 0; i < 5; i++)
 					{
-						const float l = r[18 + q * 3 + 0] * u[2] + r[18 + q * 3 + 1] * u[3] + r[18 + q * 3 + 2] * u[4];
-						leaf2[4 + q] = l * l;
-					}
-				}
-				if constexpr (HAS_HINV)
-				{
-					float add = FOLD3 ? leaf2[3] : leaf2[3] * r[HO + 3];
+						float ti = 0.f;
 #pragma unroll
-					for (int c = 0; c < C; c++)
-						if (c != 3) add += leaf2[c] * r[HO + c];
+						for (int j = i; j < 5; j++) ti += r[q++] * u[j];
+						add += u[i] * ti;
+					}
 					score += has ? w2 * add : 0.f;
 				}
+				float leaf2[C];
+				if constexpr (!QFORM)
+				{
+#pragma unroll
+					for (int q = 0; q < 3; q++)
+					{
+						const float l = r[3 + q * 5 + 0] * u[0] + r[3 + q * 5 + 1] * u[1] + r[3 + q * 5 + 2] * u[2]
+						              + r[3 + q * 5 + 3] * u[3] + r[3 + q * 5 + 4] * u[4];
+						leaf2[q] = l * l;
+					}
+					leaf2[3] = r[KO];
+					if constexpr (C == 11)
+					{
+#pragma unroll
+						for (int q = 0; q < 7; q++)
+						{
+							const float l = r[18 + q * 3 + 0] * u[2] + r[18 + q * 3 + 1] * u[3] + r[18 + q * 3 + 2] * u[4];
+							leaf2[4 + q] = l * l;
+						}
+					}
+					if constexpr (HAS_HINV)
+					{
+						float add = FOLD3 ? leaf2[3] : leaf2[3] * r[HO + 3];
+#pragma unroll
+						for (int c = 0; c < C; c++)
+							if (c != 3) add += leaf2[c] * r[HO + c];
+						score += has ? w2 * add : 0.f;
+					}
+				}
+				(void)leaf2;
 				if constexpr (HAS_OUTH)
 				{
 					if (has)
