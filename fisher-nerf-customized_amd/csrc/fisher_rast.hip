@@ -1247,10 +1247,10 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 	__shared__ float s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];
 	constexpr int PS = FrPackSize<C>::value;
 	// per-entry registers of pass 2: rgb[3], A'[15], (Cm'[21]), k3, [H_inv columns]
-	// QFORM (11 columns, score only): the weighted sum of squared leaves is a quadratic form in u',
+	// QFORM (score only): the weighted sum of squared leaves is a quadratic form in u',
 	//   sum_c H_inv[c] (M_c . u')^2 = u'^T Q u',  Q = sum_c H_inv[c] M_c^T M_c  (5 x 5 symmetric, 15 numbers),
 	// so the walk fetches rgb[3], Q[15], k3 instead of 51 values per entry, whatever the number of columns.
-	constexpr bool QFORM = (C == 11) && HAS_HINV && !HAS_OUTH;
+	constexpr bool QFORM = HAS_HINV && !HAS_OUTH;
 	constexpr int KO = QFORM ? 18 : ((C == 11) ? 39 : 18);   // offset of k3 = 1/opacity^2 (times H_inv[3] when only the score is wanted)
 	constexpr int HO = KO + 1;                    // offset of the H_inv columns
 	constexpr bool FOLD3 = HAS_HINV && !HAS_OUTH; // H_inv[3] folded into k3
@@ -1486,10 +1486,13 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 					for (int j = i; j < 5; j++)
 					{
 						float acc = hv[0] * Ap[0][i] * Ap[0][j] + hv[1] * Ap[1][i] * Ap[1][j] + hv[2] * Ap[2][i] * Ap[2][j];
-						if (i >= 2)
+						if constexpr (C == 11)
 						{
+							if (i >= 2)
+							{
 #pragma unroll
-							for (int r = 0; r < 7; r++) acc += hv[4 + r] * Cp[r][i - 2] * Cp[r][j - 2];
+								for (int r = 0; r < 7; r++) acc += hv[4 + r] * Cp[r][i - 2] * Cp[r][j - 2];
+							}
 						}
 						b[q++] = (i == j) ? acc : 2.0f * acc;
 					}
