@@ -1935,9 +1935,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 	__syncthreads();
 
 	// ---- pass 1 (same as k_fisher_tile_v2): transmittance, last contributor, per-wave list ----
-	bool done = !inside;
+	// wave votes as 64-bit scalar masks (v_cmp -> SGPR pair), like k_fisher_tile_v2; the arithmetic is the forward pass's
+	unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
 	float T = 1.0f;
-	int last = 0;
+	int last = 0;                                  // 1 + index in this wave's list of the pixel's last contributor
 	int wcnt = 0;
 	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
 	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
@@ -1970,26 +1971,28 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(thr_l, j);
 			const float dx = x - pfx, dy = y - pfy;
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-			const bool pass = !done && !(power > 0.0f) && !(power < thr);
-			if (__any(pass))
+			const unsigned long long skip_m = __builtin_amdgcn_fcmpf(power, 0.0f, 2 /* ogt */) | __builtin_amdgcn_fcmpf(power, thr, 4 /* olt */);
+			const unsigned long long pass_m = ~(skip_m | done_m);
+			if (pass_m)
 			{
 				const float G = fr_expf_inrange(power);
 				const float alpha = fminf(0.99f, o * G);
-				const bool ok = pass && !(alpha < 1.0f / 255.0f);
+				const unsigned long long ok_m = pass_m & ~__builtin_amdgcn_fcmpf(alpha, 1.0f / 255.0f, 4 /* olt */);
 				const float test_T = T * (1 - alpha);
-				const bool kill = ok && (test_T < 0.0001f);
-				const bool contrib = ok && !kill;
-				done = done || kill;
-				T = contrib ? test_T : T;
-				last = contrib ? ((int)base + j + 1) : last;
-				if (__any(contrib))
+				const unsigned long long kill_m = ok_m & __builtin_amdgcn_fcmpf(test_T, 0.0001f, 4 /* olt */);
+				const unsigned long long contrib_m = ok_m & ~kill_m;
+				done_m |= kill_m;
+				if (contrib_m)
 				{
+					const bool contrib = __builtin_amdgcn_inverse_ballot_w64(contrib_m);
+					T = contrib ? test_T : T;
+					last = contrib ? (wcnt + 1) : last;
 					if (wcnt < FR_WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
 					wcnt = __builtin_amdgcn_readfirstlane(wcnt + 1);
 				}
 			}
 		}
-		if (__all(done)) break;
+		if (done_m == ~0ull) break;
 	}
 	if (lane == 0 && wcnt > FR_WCAP) s_ovf = 1;
 	__syncthreads();
@@ -2066,23 +2069,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 		}
 		unsigned long long mask = fr_wave_transpose64(emask, lane);
 		{
-			int t = 0;
-#pragma unroll
-			for (int step = 32; step >= 1; step >>= 1)
-			{
-				const int probe = t + step - 1;
-				const int kp = __builtin_amdgcn_ds_bpermute((probe & 63) << 2, kk);
-				if (probe < 64 && kp >= last) t += step;
-			}
-			mask = (t >= 64) ? 0ull : (mask & ~((1ull << t) - 1ull));
+			// lane l owns list index hi-1-l; the pixel's contributors are the indices below `last`
+			const int t = hi - last;
+			mask = (t >= 64) ? 0ull : (t > 0) ? (mask & ~((1ull << t) - 1ull)) : mask;
 			if (!inside) mask = 0ull;
 		}
-		while (__any(mask != 0ull))
+		while (fr_any(mask != 0ull))
 		{
 			bool has = mask != 0ull;
 			const int j = has ? (__ffsll((long long)mask) - 1) : 0;
 			mask &= mask - 1ull;
-			const int kj = __builtin_amdgcn_ds_bpermute(j << 2, kk);
 			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
 			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
 			const float o = fr_bperm_f(ao, j), thr = fr_bperm_f(athr, j);
@@ -2091,7 +2087,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
 			const float G = fr_expf_inrange(power);
 			const float alpha = fminf(0.99f, o * G);
-			has = has && (kj < last) && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);
+			has = has && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);
 			if (has)
 			{
 				float m2x, m2y, qx, qy, qw, wcol, gop;
