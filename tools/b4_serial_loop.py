@@ -4,7 +4,7 @@
 cat, sum(...).item()), i.e. per-view allocations and host syncs, using this repository's own kernels.
 Prints views/s; this is the "1x" the batched scorer's speed-up is quoted against (no CUDA number exists)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "fisher-nerf-customized_amd")):
     sys.path.insert(0, p)
 import numpy as np, torch
