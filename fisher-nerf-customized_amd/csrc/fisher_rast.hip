@@ -944,6 +944,8 @@ __device__ __forceinline__ unsigned long long fr_wave_transpose64(unsigned long 
 // Fused Fisher scorer: one workgroup per (tile, view).
 struct FrFisherArgs {
 	float dL;                    // constant upstream gradient
+	const float* dL_img;         // or per view an upstream-gradient image [V][3][H][W] (out_H modes only), stride in floats
+	long long dL_stride;
 	const float* H_inv; long long hinv_stride;
 	float* out_H; long long outH_stride;
 	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
@@ -1040,8 +1042,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 	st.accum0 = st.accum1 = st.accum2 = 0.f;
 	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
 	st.last_alpha = 0.f;
-	const float g = f.dL;
-	const float bg_dot = p.bg[0] * g + p.bg[1] * g + p.bg[2] * g;
+	float g0 = f.dL, g1 = f.dL, g2 = f.dL;
+	if constexpr (HAS_OUTH)
+	{
+		if (f.dL_img)
+		{
+			const size_t HW = (size_t)p.H * p.W, pix = (size_t)p.W * pxy + pxx;
+			const float* gi = f.dL_img + (size_t)v * f.dL_stride;
+			g0 = inside ? gi[pix] : 0.f; g1 = inside ? gi[HW + pix] : 0.f; g2 = inside ? gi[2 * HW + pix] : 0.f;
+		}
+	}
+	const float bg_dot = p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2;
 	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
 	float score = 0.f;
 
@@ -1109,7 +1120,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 			{
 				float m2x, m2y, qx, qy, qw, wcol, gop;
 				fr_pair_backward(st, alpha, G, dx, dy, co.x, co.y, co.z, co.w,
-				                 s_rgb[0][j], s_rgb[1][j], s_rgb[2][j], g, g, g, bg_dot, ddelx_dx, ddely_dy,
+				                 s_rgb[0][j], s_rgb[1][j], s_rgb[2][j], g0, g1, g2, bg_dot, ddelx_dx, ddely_dy,
 				                 m2x, m2y, qx, qy, qw, wcol, gop);
 #pragma unroll
 				for (int r = 0; r < 3; r++)
@@ -1390,8 +1401,17 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 	st.accum0 = st.accum1 = st.accum2 = 0.f;
 	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
 	st.last_alpha = 0.f;
-	const float g = f.dL;
-	const float bg_dot = p.bg[0] * g + p.bg[1] * g + p.bg[2] * g;
+	float g0 = f.dL, g1 = f.dL, g2 = f.dL;
+	if constexpr (HAS_OUTH)
+	{
+		if (f.dL_img)
+		{
+			const size_t HW = (size_t)p.H * p.W, pix = (size_t)p.W * pxy + pxx;
+			const float* gi = f.dL_img + (size_t)v * f.dL_stride;
+			g0 = inside ? gi[pix] : 0.f; g1 = inside ? gi[HW + pix] : 0.f; g2 = inside ? gi[2 * HW + pix] : 0.f;
+		}
+	}
+	const float bg_dot = p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2;
 	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
 	float score = 0.f;
 	const uint16_t* wl = s_wl[wave];
@@ -1598,7 +1618,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 				st.accum0 = st.last_alpha * st.lastc0 + ola * st.accum0; st.lastc0 = r[0];
 				st.accum1 = st.last_alpha * st.lastc1 + ola * st.accum1; st.lastc1 = r[1];
 				st.accum2 = st.last_alpha * st.lastc2 + ola * st.accum2; st.lastc2 = r[2];
-				float dL_dalpha = ((r[0] - st.accum0) * g + (r[1] - st.accum1) * g + (r[2] - st.accum2) * g) * st.T;
+				float dL_dalpha = ((r[0] - st.accum0) * g0 + (r[1] - st.accum1) * g1 + (r[2] - st.accum2) * g2) * st.T;
 				st.last_alpha = alpha;
 				if (bg_dot != 0.f) dL_dalpha += (-st.T_final * inv) * bg_dot;
 				const float w = a_un * dL_dalpha;                                     // opacity * G * dL_dalpha
@@ -2711,6 +2731,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	if (fc->out_scores && !fc->H_inv) return fr_fail(FR_EINVAL, "fr_fisher_views: out_scores needs H_inv");
 	if (!fc->H_inv && !fc->out_H) return fr_fail(FR_EINVAL, "fr_fisher_views: nothing to compute (no H_inv and no out_H)");
 	if (fc->H_inv && !fc->out_scores) return fr_fail(FR_EINVAL, "fr_fisher_views: H_inv without out_scores");
+	if (fc->dL_dpix_image && (fc->H_inv || !fc->out_H)) return fr_fail(FR_EINVAL, "fr_fisher_views: dL_dpix_image is for the out_H mode (no H_inv)");
 	const int P = cfg->P, W = cfg->image_width, H = cfg->image_height, V = fc->n_views;
 	hipStream_t s = (hipStream_t)stream;
 	if (P == 0)
@@ -2746,6 +2767,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 
 	FrFisherArgs f;
 	f.dL = fc->dL_dpix;
+	f.dL_img = fc->dL_dpix_image; f.dL_stride = fc->dL_image_view_stride;
 	f.H_inv = fc->H_inv; f.hinv_stride = fc->H_inv_view_stride;
 	f.out_H = fc->out_H; f.outH_stride = fc->out_H_view_stride;
 	f.tile_scores = (float*)(ws + L.tile_scores);

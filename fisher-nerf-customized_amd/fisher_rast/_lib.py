@@ -58,6 +58,8 @@ class FisherCfg(ctypes.Structure):
         ("out_H_view_stride", ctypes.c_int64),
         ("out_vis_count", ctypes.c_void_p),
         ("out_num_rendered", ctypes.c_void_p),
+        ("dL_dpix_image", _f32p),
+        ("dL_image_view_stride", ctypes.c_int64),
     ]
 
 

@@ -281,7 +281,7 @@ class FisherScorer:
             ws = self._ws[slot] = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
         return ws
 
-    def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False):
+    def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None):
         """Enqueue one batch (no sync).  w2c: [V,4,4] world->camera on the device.
         Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4].
 
@@ -304,6 +304,14 @@ class FisherScorer:
             want = (V * PC) if out_H_per_view else PC
             if out_H.numel() != want or out_H.dtype != torch.float32 or not out_H.is_contiguous() or out_H.device != d:
                 raise ValueError("out_H must be a contiguous fp32 device tensor of [V,]P*columns elements")
+        HW3 = 3 * int(self.rs.image_height) * int(self.rs.image_width)
+        if dL_image is not None:
+            # per view an upstream-gradient image [V,3,H,W] (or one [3,H,W] shared): the random probes of the POp-GS estimators
+            if out_H is None or H_inv is not None:
+                raise ValueError("dL_image goes with out_H (no H_inv)")
+            dL_image = _prep(dL_image, d)
+            if dL_image.numel() not in (HW3, V * HW3):
+                raise ValueError(f"dL_image has {dL_image.numel()} elements, expected {HW3} or {V * HW3}")
         vis = torch.zeros((V,), dtype=torch.int32, device=d)
         nr = torch.zeros((V,), dtype=torch.int32, device=d)
         n_groups = self.n_streams if (V >= 16 * self.n_streams and V % (8 * self.n_streams) == 0) else 1
@@ -331,6 +339,10 @@ class FisherScorer:
                 if out_H is not None:
                     fc.out_H = ctypes.c_void_p(out_H.data_ptr() + (v0 * PC * 4 if out_H_per_view else 0))
                     fc.out_H_view_stride = PC if out_H_per_view else 0
+                if dL_image is not None:
+                    per_view = dL_image.numel() != HW3
+                    fc.dL_dpix_image = ctypes.c_void_p(dL_image.data_ptr() + (v0 * HW3 * 4 if per_view else 0))
+                    fc.dL_image_view_stride = HW3 if per_view else 0
                 fc.out_vis_count = vis.data_ptr() + v0 * 4
                 fc.out_num_rendered = nr.data_ptr() + v0 * 4
                 _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
@@ -343,9 +355,9 @@ class FisherScorer:
             status = torch.stack([status[:, 0].sum(), status[:, 1].max(), status[:, 2].max(), status[:, 3].max()]).to(torch.int32)
         else:
             status = status[0]
-        return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv))
+        return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv, dL_image))
 
-    def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False):
+    def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None):
         """launch() + overflow handling.  Synchronises once (to read the 16-byte status word)."""
         w2c = w2c.reshape(-1, 4, 4)
         V = int(w2c.shape[0])
@@ -362,7 +374,10 @@ class FisherScorer:
                 oh = out_H.view(V, -1)[v0:v1]
             snapshot = oh.clone() if oh is not None else None
             while True:
-                r = self.launch(w2c[v0:v1], hi, H_inv_per_view, oh, out_H_per_view)
+                dl = dL_image
+                if dL_image is not None and dL_image.dim() == 4 and dL_image.shape[0] == V:
+                    dl = dL_image[v0:v1]
+                r = self.launch(w2c[v0:v1], hi, H_inv_per_view, oh, out_H_per_view, dl)
                 st = r["status"].cpu()
                 if int(st[1]) == 0:
                     break

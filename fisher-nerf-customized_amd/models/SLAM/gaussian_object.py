@@ -9,6 +9,10 @@
       the power-2 rasteriser, squares of those gradients averaged -- the reference's own quirk).
   estimate_block_JtJ (2111-2176), compute_H_train_blocks (1572-1585), pose_eval_popgs_blocks (1660-1704),
   t_opt_blocks / d_opt_blocks (1721-1732): the per-splat d x d block form of the same criteria (d <= 11), same route.
+  Fused route (default, `fused=True`): the K probes `im.backward(gradient=z_k)` on the power-2 rasteriser are K "views" of
+      the batched Fisher kernel with a per-view upstream-gradient IMAGE (fr_fisher_cfg.dL_dpix_image) and per-view
+      `out_H` -- one launch for all probes (and, in pose_eval_popgs, for all poses), no autograd graph, no K generic
+      backward passes.  Same numbers as the autograd route within the scorer's 1e-4 bar.
 """
 import numpy as np
 import torch
@@ -21,12 +25,36 @@ from models.SLAM.gaussian import FisherOps, GaussianSLAM
 class ObjectFisherOps(FisherOps):
     FISHER_COLUMNS = 11
 
+    # ---- fused probes -------------------------------------------------------------------------------------------
+    def _draw_probes(self, n, zs=None):
+        """[n,3,H,W] upstream gradients: the reference draws `torch.randn_like(im)` per probe (2088, 2158)."""
+        dev = self._device()
+        H, W = int(self.cam.image_height), int(self.cam.image_width)
+        if zs is not None:
+            return torch.stack([z.to(dev).float() for z in zs]).reshape(n, 3, H, W)
+        return torch.randn((n, 3, H, W), device=dev)
+
+    def _probe_rows(self, w2cs, zs):
+        """Power-2 gradient rows of the rasteriser under upstream images zs [V,3,H,W] at poses w2cs [V,4,4]:
+        rows [V,N,11] in the Fisher column order [mean3 | opacity | scale3 | rot4], and vis_count [V]."""
+        scorer = self._scorer()
+        V = int(w2cs.shape[0])
+        rows = torch.zeros((V, scorer.P, 11), dtype=torch.float32, device=self._device())
+        res = scorer.run(w2cs, out_H=rows, out_H_per_view=True, dL_image=zs)
+        return rows, res["vis_count"]
+
+    _DIAG_ORDER = ((0, 3), (3, 4), (7, 11), (4, 7))          # [means | opacity | rot | scale] blocks of the 11 columns
+
     @torch.enable_grad()
-    def estimate_diag_JtJ_simple(self, w2c, K: int = 4, zs=None):
+    def estimate_diag_JtJ_simple(self, w2c, K: int = 4, zs=None, fused: bool = True):
         """Returns (diag / K, vis_count), diag flat as [means(3N) | opacity(N) | rot(4N) | scale(3N)].
         `zs` (optional list of K [3,H,W] tensors) replaces the reference's `torch.randn_like(im)` draws."""
         dev = self._device()
         w2c = self._as_w2c(w2c)
+        if fused:
+            rows, vis = self._probe_rows(w2c.reshape(1, 4, 4).expand(K, 4, 4).contiguous(), self._draw_probes(K, zs))
+            g = torch.cat([rows[:, :, a:b].reshape(K, -1) for a, b in self._DIAG_ORDER], dim=1)
+            return (g * g).sum(dim=0) / float(K), int(vis[0].item())
         p = self.params
         with torch.no_grad():
             pts = p['means3D']
@@ -61,13 +89,30 @@ class ObjectFisherOps(FisherOps):
             diag_accum = contrib if diag_accum is None else diag_accum + contrib
         return diag_accum / float(K), vis_count
 
-    def compute_H_train_popgs(self, K: int = 4):
+    def _diag_batch(self, w2cs, K, chunk_bytes=4 << 30):
+        """diag(J^T J) estimates [V, 11N] for V poses, K probes each, in as few launches as memory allows."""
+        V = int(w2cs.shape[0])
+        N = int(self.params['means3D'].shape[0])
+        per = max(1, int(chunk_bytes // (K * N * 44)))
+        out = []
+        for v0 in range(0, V, per):
+            w = w2cs[v0:v0 + per]
+            n = int(w.shape[0])
+            rows, _ = self._probe_rows(w.repeat_interleave(K, dim=0), self._draw_probes(n * K))
+            g = torch.cat([rows[:, :, a:b].reshape(n, K, -1) for a, b in self._DIAG_ORDER], dim=2)
+            out.append((g * g).sum(dim=1) / float(K))
+        return torch.cat(out)
+
+    def compute_H_train_popgs(self, K: int = 4, fused: bool = True):
+        if len(self.keyframe_list) == 0:
+            raise RuntimeError("No keyframes available for POP-GS prior.")
+        if fused:
+            w2cs = torch.stack([self._as_w2c(kf['est_w2c']) for kf in self.keyframe_list])
+            return self._diag_batch(w2cs, K).sum(dim=0)
         H = None
         for kf in self.keyframe_list:
-            cur, _ = self.estimate_diag_JtJ_simple(kf['est_w2c'], K=K)
+            cur, _ = self.estimate_diag_JtJ_simple(kf['est_w2c'], K=K, fused=False)
             H = cur if H is None else H + cur
-        if H is None:
-            raise RuntimeError("No keyframes available for POP-GS prior.")
         return H
 
     @staticmethod
@@ -83,12 +128,20 @@ class ObjectFisherOps(FisherOps):
         Hpi = Hm + JtJ_diag_pi
         return torch.sum(torch.log(torch.clamp(Hpi, min=1e-12))) - torch.sum(torch.log(torch.clamp(Hm, min=1e-12)))
 
-    def pose_eval_popgs(self, poses, random_gaussian_params=None, criterion: str = "topt", K: int = 4, lam: float = 1e-6):
-        H_train_diag = self.compute_H_train_popgs(K=K)
+    def pose_eval_popgs(self, poses, random_gaussian_params=None, criterion: str = "topt", K: int = 4, lam: float = 1e-6,
+                        fused: bool = True):
+        if criterion.lower() not in ("topt", "dopt"):
+            raise ValueError("criterion must be 'topt' or 'dopt'")
+        H_train_diag = self.compute_H_train_popgs(K=K, fused=fused)
+        if fused:
+            c2w_all = torch.stack([self._as_w2c(c2w) for c2w in poses])
+            diags = self._diag_batch(torch.linalg.inv(c2w_all), K)
+            fn = self.topt_score_from_diags if criterion.lower() == "topt" else self.dopt_score_from_diags
+            return torch.tensor([float(fn(H_train_diag, d, lam=lam)) for d in diags]), c2w_all
         scores, c2ws = [], []
         for c2w in poses:
             c2w = self._as_w2c(c2w)
-            cur_diag, _ = self.estimate_diag_JtJ_simple(torch.linalg.inv(c2w), K=K)
+            cur_diag, _ = self.estimate_diag_JtJ_simple(torch.linalg.inv(c2w), K=K, fused=False)
             if criterion.lower() == "topt":
                 s = self.topt_score_from_diags(H_train_diag, cur_diag, lam=lam)
             elif criterion.lower() == "dopt":
@@ -102,7 +155,7 @@ class ObjectFisherOps(FisherOps):
     # ---- block form (gaussian_object.py:2111-2176, 1572-1585, 1660-1732) ------------------------------------------
     @torch.enable_grad()
     def estimate_block_JtJ(self, w2c, K: int = 2, use_rot: bool = True, use_scale: bool = True, use_opacity: bool = True,
-                           zs=None):
+                           zs=None, fused: bool = True):
         """Returns (H_blocks [Nv, d, d] / K, vis_idx [Nv]): per visible splat the outer product of its power-2 gradient
         row [mean3 | opacity | rot4 | scale3] (columns present as the flags say), averaged over K random upstream draws.
         `zs` (optional list of K [3,H,W] tensors) replaces the reference's `torch.randn_like(im)` draws."""
@@ -119,6 +172,15 @@ class ObjectFisherOps(FisherOps):
             if scales.shape[-1] == 1:
                 scales = scales.repeat(1, 3)
             colors = p['rgb_colors']
+        if fused:
+            with torch.no_grad():            # one forward for the visible set (radius > 0), then all probes in one launch
+                _, radius, _ = Renderer(raster_settings=self.cam)(means3D=transformed_pts, means2D=torch.zeros_like(transformed_pts),
+                                                                  opacities=opacities, colors_precomp=colors, scales=scales, rotations=rotations)
+            vis_idx = torch.where(radius > 0)[0]
+            rows, _ = self._probe_rows(w2c.reshape(1, 4, 4).expand(int(K), 4, 4).contiguous(), self._draw_probes(int(K), zs))
+            cols = [0, 1, 2] + ([3] if use_opacity else []) + ([7, 8, 9, 10] if use_rot else []) + ([4, 5, 6] if use_scale else [])
+            Gv = rows[:, vis_idx][:, :, cols]                                  # [K, Nv, d] in the order [mean | opacity | rot | scale]
+            return torch.einsum('kvi,kvj->vij', Gv, Gv) / float(K), vis_idx
         rvars = {
             'means3D': transformed_pts.requires_grad_(True),
             'rotations': rotations.detach().clone().requires_grad_(use_rot),
@@ -158,7 +220,7 @@ class ObjectFisherOps(FisherOps):
         """Sum over keyframes, aligned the reference's way (truncate to the smaller visible count, keep the first index set)."""
         Hm, vis_ref = None, None
         for kf in self.keyframe_list:
-            Hb, vis_idx = self.estimate_block_JtJ(kf['est_w2c'], K=K, **kw)
+            Hb, vis_idx = self.estimate_block_JtJ(kf['est_w2c'], K=K, **kw)          # (kw may carry fused=False)
             if Hm is None:
                 Hm, vis_ref = Hb, vis_idx
             else:

@@ -155,6 +155,10 @@ typedef struct fr_fisher_cfg {
 	int64_t out_H_view_stride;  /* elements between views' blocks in out_H (0 = all views sum into one block) */
 	int32_t* out_vis_count;     /* device [n_views]: #Gaussians with radius > 0, or null */
 	int32_t* out_num_rendered;  /* device [n_views]: tile instances per view, or null */
+	const float* dL_dpix_image; /* device [n_views,3,H,W] or null: per view an upstream-gradient image instead of the constant
+	                               dL_dpix -- the `im.backward(gradient=z)` probes of estimate_diag_JtJ_simple /
+	                               estimate_block_JtJ (gaussian_object.py:2088-2098, 2158-2170).  out_H mode only. */
+	int64_t dL_image_view_stride; /* elements between views' images (0 = one image shared by all views) */
 } fr_fisher_cfg;
 
 size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);

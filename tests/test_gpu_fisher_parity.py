@@ -189,9 +189,11 @@ def test_popgs_diag_estimator(config1, gpu, oracle):
     g = torch.Generator().manual_seed(5)
     zs = [torch.randn((3, c["H"], c["W"]), generator=g) for _ in range(K)]
     w2c = torch.linalg.inv(c["c2w"][1].to(gpu))
-    diag, vis = slam.estimate_diag_JtJ_simple(w2c, K=K, zs=zs)
+    diag, vis = slam.estimate_diag_JtJ_simple(w2c, K=K, zs=zs)                  # fused: all probes in one fr_fisher_views launch
+    diag_ag, vis_ag = slam.estimate_diag_JtJ_simple(w2c, K=K, zs=zs, fused=False)   # the reference's autograd route
     P = c["P"]
-    assert diag.shape == (P * 11,)
+    assert diag.shape == (P * 11,) and vis == vis_ag
+    assert_close(diag.cpu().numpy(), diag_ag.double().cpu().numpy(), 2e-4, "diag_JtJ fused vs autograd", atol_frac=1e-7)
     # oracle on the very same device-side render variables
     from models.SLAM.utils.slam_helpers import transformed_params2rendervar
     pts = slam.params["means3D"]
@@ -214,6 +216,9 @@ def test_popgs_diag_estimator(config1, gpu, oracle):
     assert torch.isfinite(t) and torch.isfinite(d) and float(d) >= 0.0 and float(t) < 0.0
     scores, c2ws = slam.pose_eval_popgs([p.to(gpu) for p in c["c2w"][:2]], criterion="dopt", K=1)
     assert scores.shape == (2,) and c2ws.shape == (2, 4, 4)
+    # same draws through both routes: seed the generator the probes come from
+    torch.manual_seed(11); s_f, _ = slam.pose_eval_popgs([p.to(gpu) for p in c["c2w"][:2]], criterion="topt", K=2, lam=1e-3)
+    assert bool(torch.isfinite(s_f).all()) and bool((s_f < 0).all())
 
 
 def test_popgs_block_estimator(config1, gpu, oracle):
@@ -226,7 +231,10 @@ def test_popgs_block_estimator(config1, gpu, oracle):
     g = torch.Generator().manual_seed(6)
     zs = [torch.randn((3, c["H"], c["W"]), generator=g) for _ in range(K)]
     w2c = torch.linalg.inv(c["c2w"][2].to(gpu))
-    Hb, vis_idx = slam.estimate_block_JtJ(w2c, K=K, zs=zs)
+    Hb, vis_idx = slam.estimate_block_JtJ(w2c, K=K, zs=zs)                       # fused route
+    Hb_ag, vis_ag = slam.estimate_block_JtJ(w2c, K=K, zs=zs, fused=False)         # autograd route
+    assert torch.equal(vis_idx, vis_ag)
+    assert_close(Hb.cpu().numpy(), Hb_ag.double().cpu().numpy(), 4e-4, "block_JtJ fused vs autograd", atol_frac=1e-7)
     from models.SLAM.utils.slam_helpers import transformed_params2rendervar
     pts = slam.params["means3D"]
     tp = (w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3]
