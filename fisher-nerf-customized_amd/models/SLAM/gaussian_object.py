@@ -270,6 +270,17 @@ class ObjectFisherOps(FisherOps):
             c2ws.append(c2w)
         return torch.tensor(scores), torch.stack(c2ws)
 
+    @classmethod
+    def install(cls, target_cls):
+        """Graft the 11-column Fisher methods AND the POp-GS estimators onto the reference's GaussianObjectSLAM."""
+        target_cls.FISHER_COLUMNS = cls.FISHER_COLUMNS
+        super().install(target_cls)
+        for name in ("_draw_probes", "_probe_rows", "_diag_batch", "_DIAG_ORDER", "estimate_diag_JtJ_simple",
+                     "compute_H_train_popgs", "pose_eval_popgs", "estimate_block_JtJ", "compute_H_train_blocks",
+                     "pose_eval_popgs_blocks"):
+            setattr(target_cls, name, cls.__dict__[name])
+        return target_cls
+
 
 class GaussianObjectSLAM(ObjectFisherOps, GaussianSLAM):
     pass

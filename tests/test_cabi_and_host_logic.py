@@ -160,3 +160,29 @@ def test_setup_camera_matches_oracle_restatement(oracle):
     # identity camera at 256x256: p_hom.w = z and pixel = 128 x/z + 127.5
     pm = setup_camera(256, 256, K, np.eye(4), device="cpu").projmatrix.reshape(-1).numpy()
     assert np.allclose(pm[[0, 5, 11]], [1, 1, 1]) and np.allclose(pm[[3, 7, 15]], [0, 0, 0])
+
+
+def test_install_grafts_methods_onto_reference_like_classes():
+    """INTEGRATION.md sections 4 / 4b: `install` puts the accelerated methods on classes that merely look like the reference's."""
+    from models.SLAM.gaussian import FisherOps
+    from models.SLAM.gaussian_object import ObjectFisherOps
+    from planning.astar import OccupancyOps
+
+    class RefSLAM:
+        pass
+
+    class RefObjectSLAM:
+        def topt_score_from_diags(self, *a, **k):
+            return 1
+
+    class RefPlanner:
+        pass
+
+    FisherOps.install(RefSLAM)
+    assert RefSLAM.FISHER_COLUMNS == 4 and all(callable(getattr(RefSLAM, n)) for n in ("compute_Hessian", "compute_H_train", "pose_eval", "path_scores"))
+    ObjectFisherOps.install(RefObjectSLAM)
+    assert RefObjectSLAM.FISHER_COLUMNS == 11 and RefObjectSLAM._DIAG_ORDER[0] == (0, 3)
+    assert all(callable(getattr(RefObjectSLAM, n)) for n in ("pose_eval", "estimate_diag_JtJ_simple", "estimate_block_JtJ", "pose_eval_popgs", "pose_eval_popgs_blocks"))
+    assert RefObjectSLAM().topt_score_from_diags() == 1                       # the reference's own helpers are left alone
+    OccupancyOps.install(RefPlanner)
+    assert all(callable(getattr(RefPlanner, n)) for n in ("update_occ_map", "build_connected_freespace", "build_frontiers", "generate_candidate"))
