@@ -16,7 +16,8 @@ if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     out["hbm_bytes_per_launch"] = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
     out["note"] = ("separate --pmc passes (profiles/%s_pmc_*.csv); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM "
                    "section (FETCH_SIZE halves wide streaming reads on gfx950; this kernel's 8-32 B gathers are not a calibrated access shape)" % tag)
-for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):
+for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+          "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"):
     if k in m: out[k] = m[k]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 json.dump(out, open(os.path.join(root, "profiles", "pmc_k_fisher_tile_v2.json"), "w"), indent=1)
