@@ -352,3 +352,40 @@ def test_more_tiles_than_the_lds_histogram_holds(gpu, oracle):
     sc.run(torch.from_numpy(w2c[None]).to(gpu), out_H=cur)
     H_o, _ = oracle.compute_hessian(cam, w2c, act["means3D"], act["rgb_colors"], act["rotations"], act["opacities"], act["scales"])
     assert_close(cur.cpu().numpy(), H_o, 1e-4, "cur_H", atol_frac=1e-7)
+
+
+@pytest.mark.parametrize("P,V,W,H,columns,seed", [
+    (2, 1, 32, 32, 4, 40),            # two Gaussians, one view
+    (63, 3, 50, 70, 4, 41),           # fewer Gaussians than a wave, ragged image, V < views per preprocess workgroup
+    (300, 9, 72, 40, 11, 42),         # V = 8 + 1: a second, partial view chunk
+    (777, 17, 48, 48, 4, 43),         # V odd: plain tile mapping (V % 8 != 0)
+    (2500, 8, 96, 64, 11, 44),
+    (1800, 5, 33, 17, 4, 45),         # image smaller than two tiles in one direction
+])
+def test_odd_shapes_against_oracle(gpu, oracle, P, V, W, H, columns, seed):
+    """Shapes around the decomposition boundaries of the multi-view front end (256 Gaussians x 8 views per workgroup),
+    the XCD-aware tile mapping (V % 8) and the 16 x 16 tiling."""
+    from fisher_rast import synthetic
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    act = synthetic.activate(synthetic.room_shell(P, seed))
+    K = synthetic.intrinsics(W, H)
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(V, seed))
+    kf = synthetic.invert_rigid(synthetic.candidate_poses(2, seed + 100))
+    cam = setup_camera(W, H, K, np.eye(4), device=gpu)
+    ocam = oracle.setup_camera(W, H, K, np.eye(4))
+    a = {k: v.numpy() for k, v in act.items()}
+    args = (a["means3D"], a["rgb_colors"], a["rotations"], a["opacities"], a["scales"])
+    sc = FisherScorer(cam, *(act[k].to(gpu) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")), columns=columns)
+    Ht = torch.zeros((P, columns), device=gpu)
+    sc.run(kf.to(gpu), out_H=Ht)
+    H_train_o = oracle.compute_h_train(ocam, kf.numpy(), *args, columns=columns)
+    assert_close(Ht.cpu().numpy(), H_train_o, 1e-4, "H_train", atol_frac=1e-7)
+    r = sc.run(w2c.to(gpu), H_inv=torch.reciprocal(Ht + 0.1))
+    want, vis = oracle.pose_eval(ocam, w2c.numpy(), H_train_o, *args, columns=columns)
+    assert np.array_equal(r["vis_count"].cpu().numpy(), vis)
+    got = r["scores"].cpu().numpy()
+    assert np.all(np.abs(got - want) <= 1e-4 * np.maximum(np.abs(want), 1e-30) + 1e-12 * np.abs(want).max()), (got, want)
+    for v in range(min(V, 3)):
+        _, _, fwd, _ = oracle.compute_hessian(ocam, w2c[v].numpy(), *args, columns=columns, return_all=True)
+        assert int(r["num_rendered"][v]) == fwd["num_rendered"]
