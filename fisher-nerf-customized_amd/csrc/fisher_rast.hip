@@ -2353,6 +2353,31 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 }
 
 // Launches cov3d, preprocess, scan, scatter, sort for V views.  p must carry the carved buffers.
+// One launch instead of a dozen memsets: zero-fills up to FR_ZERO_MAX device buffers (all sizes multiples of 4 bytes).
+#define FR_ZERO_MAX 12
+struct FrZeroList { uint32_t* ptr[FR_ZERO_MAX]; unsigned long long end[FR_ZERO_MAX]; int n; };   // end[i]: prefix sum of dwords
+__global__ __launch_bounds__(FR_THREADS) void k_zero_many(FrZeroList z)
+{
+	const unsigned long long total = z.end[z.n - 1];
+	for (unsigned long long i = (unsigned long long)blockIdx.x * FR_THREADS + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * FR_THREADS)
+	{
+		int b = 0;
+		while (i >= z.end[b]) b++;
+		z.ptr[b][i - (b ? z.end[b - 1] : 0ull)] = 0u;
+	}
+}
+struct FrZeroer {
+	FrZeroList z; unsigned long long run = 0;
+	FrZeroer() { z.n = 0; }
+	void add(void* p, size_t bytes) { if (!p || bytes == 0) return; z.ptr[z.n] = (uint32_t*)p; run += bytes / 4; z.end[z.n] = run; z.n++; }
+	void launch(hipStream_t s)
+	{
+		if (z.n == 0) return;
+		const unsigned long long blocks = (run + FR_THREADS * 4 - 1) / (FR_THREADS * 4);
+		hipLaunchKernelGGL(k_zero_many, dim3((unsigned)(blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks))), dim3(FR_THREADS), 0, s, z);
+	}
+};
+
 // One side stream per host thread for the fork/join inside fr_bin_pipeline (created on first use, lives with the thread).
 struct FrSideStream {
 	hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; int device = -1;
@@ -2378,10 +2403,12 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 {
 	int rc;
 	const int P = p.P;
-	(void)hipMemsetAsync(p.tile_cnt, 0, (size_t)p.V * p.T * 4, s);
-	(void)hipMemsetAsync(p.status, 0, 16, s);
-	(void)hipMemsetAsync(p.big_list, 0, 64, s);
-	if (p.vis_count) (void)hipMemsetAsync(p.vis_count, 0, (size_t)p.V * 4, s);
+	{
+		FrZeroer z;
+		z.add(p.tile_cnt, (size_t)p.V * p.T * 4); z.add(p.status, 16); z.add(p.big_list, 64);
+		if (p.vis_count) z.add(p.vis_count, (size_t)p.V * 4);
+		z.launch(s);
+	}
 	if (g->cov3D_precomp) p.cov3D = g->cov3D_precomp;
 	else
 	{
@@ -2493,15 +2520,14 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	    !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_dconic)
 		return fr_fail(FR_EINVAL, "fr_backward: null pointer");
 	if (g->shs && !dL_dsh) return fr_fail(FR_EINVAL, "fr_backward: dL_dsh is null although SHs were given");
-	(void)hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s);
-	(void)hipMemsetAsync(dL_dmeans3D, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dcov3D, 0, (size_t)P * 6 * 4, s);
-	(void)hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_drotations, 0, (size_t)P * 4 * 4, s);
-	(void)hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * 4, s);
-	if (dL_dsh && cfg->sh_coeffs > 0) (void)hipMemsetAsync(dL_dsh, 0, (size_t)P * cfg->sh_coeffs * 3 * 4, s);
+	{
+		FrZeroer z;
+		z.add(dL_dmeans2D, (size_t)P * 3 * 4); z.add(dL_dcolors, (size_t)P * 3 * 4); z.add(dL_dopacity, (size_t)P * 4);
+		z.add(dL_dmeans3D, (size_t)P * 3 * 4); z.add(dL_dcov3D, (size_t)P * 6 * 4); z.add(dL_dscales, (size_t)P * 3 * 4);
+		z.add(dL_drotations, (size_t)P * 4 * 4); z.add(dL_dconic, (size_t)P * 4 * 4);
+		if (dL_dsh && cfg->sh_coeffs > 0) z.add(dL_dsh, (size_t)P * cfg->sh_coeffs * 3 * 4);
+		z.launch(s);
+	}
 
 	FrLayout L = fr_layout(P, W, H, 1, 1);
 	FrParams p;
@@ -2600,16 +2626,14 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	    !dL_dmeans2D_features || !dL_dcolors || !dL_dfeatures || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
 	    !dL_drotations || !dL_dconic)
 		return fr_fail(FR_EINVAL, "fr_backward_pair: null pointer");
-	(void)hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dmeans2D_features, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dfeatures, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s);
-	(void)hipMemsetAsync(dL_dmeans3D, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_dcov3D, 0, (size_t)P * 6 * 4, s);
-	(void)hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * 4, s);
-	(void)hipMemsetAsync(dL_drotations, 0, (size_t)P * 4 * 4, s);
-	(void)hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * 4, s);
+	{
+		FrZeroer z;
+		z.add(dL_dmeans2D, (size_t)P * 3 * 4); z.add(dL_dmeans2D_features, (size_t)P * 3 * 4); z.add(dL_dcolors, (size_t)P * 3 * 4);
+		z.add(dL_dfeatures, (size_t)P * 3 * 4); z.add(dL_dopacity, (size_t)P * 4); z.add(dL_dmeans3D, (size_t)P * 3 * 4);
+		z.add(dL_dcov3D, (size_t)P * 6 * 4); z.add(dL_dscales, (size_t)P * 3 * 4); z.add(dL_drotations, (size_t)P * 4 * 4);
+		z.add(dL_dconic, (size_t)P * 4 * 4);
+		z.launch(s);
+	}
 	FrLayout L = fr_layout(P, W, H, 1, 1);
 	FrParams p;
 	fr_fill_params(p, cfg, g, 1);
