@@ -1738,6 +1738,8 @@ struct FrBwdArgs {
 	float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolors; float* dL_dmean3D;
 	float* dL_dcov3D; float* dL_dscale; float* dL_drot;
 	const float* dL_dmean2D_b;   // or null: screen-space gradient of a second feature image (fr_backward_pair), added in k_backward_finish
+	// second image of k_backward_lin_tile<true>
+	const float* dL_dpix2; const float* colors2; float* dL_dcolors2; float* dL_dmean2D_2;
 };
 
 __device__ __forceinline__ float fr_powi(float x, int power)
@@ -1929,10 +1931,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_tile(FrParams p, FrBwdA
 // strip, then a back-to-front walk in which every lane follows its own pixel's contributors; the 9 sums of a 64-entry
 // chunk live in LDS (ds_add_f32) and leave as one global atomic per entry and component.
 // ---------------------------------------------------------------------------------------------------------
+// PAIR: two images on the same geometry in one pass (fr_backward_pair): channels 0-2 = b.colors / b.dL_dpix, channels 3-5 =
+// b.colors2 / b.dL_dpix2.  Every leaf sums both images, except the screen-space gradient (kept apart: the densifier reads the
+// colour image's only, gaussian.py:207) and the colour gradients.
+template <bool PAIR>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, FrBwdArgs b, uint8_t* __restrict__ fallback)
 {
+	constexpr int NCH = PAIR ? 6 : 3;
+	constexpr int NACC = PAIR ? 14 : 9;          // m2x, m2y, qx, qy, qw, dcolor[NCH], dopacity, (m2x, m2y of the second image)
 	__shared__ uint16_t s_wl[4][FR_WCAP];
-	__shared__ float s_acc[4][9][64];
+	__shared__ float s_acc[4][NACC][64];
 	__shared__ int s_ovf;
 
 	if (p.status[1]) return;
@@ -2026,15 +2034,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 	// ---- pass 2: back to front, sums of u per list entry ----
 	const size_t HW = (size_t)p.H * p.W;
 	const size_t pix = (size_t)p.W * pxy + pxx;
-	FrPixState st;
-	st.T_final = inside ? T : 0.f;
-	st.T = st.T_final;
-	st.accum0 = st.accum1 = st.accum2 = 0.f;
-	st.lastc0 = st.lastc1 = st.lastc2 = 0.f;
-	st.last_alpha = 0.f;
-	float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-	if (inside) { g0 = b.dL_dpix[pix]; g1 = b.dL_dpix[HW + pix]; g2 = b.dL_dpix[2 * HW + pix]; }
-	const float bg_dot = p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2;
+	const float T_final = inside ? T : 0.f;
+	float Tc = T_final, last_alpha = 0.f;
+	float accum[NCH], lastc[NCH], g[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { accum[c] = 0.f; lastc[c] = 0.f; g[c] = 0.f; }
+	if (inside)
+	{
+		g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix];
+		if constexpr (PAIR) { g[3] = b.dL_dpix2[pix]; g[4] = b.dL_dpix2[HW + pix]; g[5] = b.dL_dpix2[2 * HW + pix]; }
+	}
+	const float bg_dot_a = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
+	const float bg_dot_b = PAIR ? (p.bg[0] * g[3] + p.bg[1] * g[4] + p.bg[2] * g[5]) : 0.f;
 	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
 	const uint16_t* wl = s_wl[wave];
 
@@ -2044,9 +2055,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 		int kk = -1;
 		uint32_t my_id = 0;
 		float ax = 0.f, ay = 0.f, acx = 0.f, acy = 0.f, acz = 0.f, ao = 0.f, athr = INFINITY, ahx = -1.f, ahy = -1.f;
-		float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+		float col[NCH];
 #pragma unroll
-		for (int c = 0; c < 9; c++) s_acc[wave][c][lane] = 0.f;
+		for (int c = 0; c < NCH; c++) col[c] = 0.f;
+#pragma unroll
+		for (int c = 0; c < NACC; c++) s_acc[wave][c][lane] = 0.f;
 		if (lane < m)
 		{
 			kk = (int)wl[hi - 1 - lane];
@@ -2056,7 +2069,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 			const uint32_t eb = __float_as_uint(a1.w);
 			ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
 			ahy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
-			c0 = b.colors[3 * (size_t)my_id]; c1 = b.colors[3 * (size_t)my_id + 1]; c2 = b.colors[3 * (size_t)my_id + 2];
+			col[0] = b.colors[3 * (size_t)my_id]; col[1] = b.colors[3 * (size_t)my_id + 1]; col[2] = b.colors[3 * (size_t)my_id + 2];
+			if constexpr (PAIR) { col[3] = b.colors2[3 * (size_t)my_id]; col[4] = b.colors2[3 * (size_t)my_id + 1]; col[5] = b.colors2[3 * (size_t)my_id + 2]; }
 		}
 		unsigned long long emask = 0ull;
 		if (lane < m && ahx >= 0.f)
@@ -2102,7 +2116,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 			const float x = fr_bperm_f(ax, j), y = fr_bperm_f(ay, j);
 			const float cx = fr_bperm_f(acx, j), cy = fr_bperm_f(acy, j), cz = fr_bperm_f(acz, j);
 			const float o = fr_bperm_f(ao, j), thr = fr_bperm_f(athr, j);
-			const float r0 = fr_bperm_f(c0, j), r1 = fr_bperm_f(c1, j), r2 = fr_bperm_f(c2, j);
+			float rc[NCH];
+#pragma unroll
+			for (int c = 0; c < NCH; c++) rc[c] = fr_bperm_f(col[c], j);
 			const float dx = x - pfx, dy = y - pfy;
 			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
 			const float G = fr_expf_inrange(power);
@@ -2110,13 +2126,40 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 			has = has && !(power > 0.0f) && !(power < thr) && !(alpha < 1.0f / 255.0f);
 			if (has)
 			{
-				float m2x, m2y, qx, qy, qw, wcol, gop;
-				fr_pair_backward_t<false>(st, alpha, G, dx, dy, cx, cy, cz, o, r0, r1, r2, g0, g1, g2, bg_dot, ddelx_dx, ddely_dy,
-				                          m2x, m2y, qx, qy, qw, wcol, gop);
-				atomicAdd(&s_acc[wave][0][j], m2x); atomicAdd(&s_acc[wave][1][j], m2y);
-				atomicAdd(&s_acc[wave][2][j], qx); atomicAdd(&s_acc[wave][3][j], qy); atomicAdd(&s_acc[wave][4][j], qw);
-				atomicAdd(&s_acc[wave][5][j], wcol * g0); atomicAdd(&s_acc[wave][6][j], wcol * g1); atomicAdd(&s_acc[wave][7][j], wcol * g2);
-				atomicAdd(&s_acc[wave][8][j], gop);
+				// backward.cu:978-1038, per image: dL_dalpha = sum_ch (c_ch - accum_ch) dL_dpix_ch T  (- T_final / (1 - alpha) bg . dL_dpix)
+				Tc = Tc / (1.f - alpha);
+				const float wcol = alpha * Tc;
+				float da = 0.f, db = 0.f;
+#pragma unroll
+				for (int c = 0; c < NCH; c++)
+				{
+					accum[c] = last_alpha * lastc[c] + (1.f - last_alpha) * accum[c];
+					lastc[c] = rc[c];
+					const float t = (rc[c] - accum[c]) * g[c];
+					if (c < 3) da += t; else db += t;
+				}
+				da *= Tc; db *= Tc;
+				last_alpha = alpha;
+				const float bgf = -T_final / (1.f - alpha);
+				if (bg_dot_a != 0.f) da += bgf * bg_dot_a;
+				if (PAIR && bg_dot_b != 0.f) db += bgf * bg_dot_b;
+				const float dL_dalpha = da + db;
+				const float dL_dG = o * dL_dalpha;
+				const float gdx = G * dx, gdy = G * dy;
+				const float dG_ddelx = -gdx * cx - gdy * cy, dG_ddely = -gdy * cz - gdx * cy;
+				// screen-space gradient of the first image (of the only image when !PAIR)
+				const float oa = PAIR ? o * da : dL_dG;
+				atomicAdd(&s_acc[wave][0][j], oa * dG_ddelx * ddelx_dx); atomicAdd(&s_acc[wave][1][j], oa * dG_ddely * ddely_dy);
+				atomicAdd(&s_acc[wave][2][j], -0.5f * gdx * dx * dL_dG); atomicAdd(&s_acc[wave][3][j], -0.5f * gdx * dy * dL_dG);
+				atomicAdd(&s_acc[wave][4][j], -0.5f * gdy * dy * dL_dG);
+#pragma unroll
+				for (int c = 0; c < NCH; c++) atomicAdd(&s_acc[wave][5 + c][j], wcol * g[c]);
+				atomicAdd(&s_acc[wave][5 + NCH][j], G * dL_dalpha);
+				if constexpr (PAIR)
+				{
+					const float ob = o * db;
+					atomicAdd(&s_acc[wave][12][j], ob * dG_ddelx * ddelx_dx); atomicAdd(&s_acc[wave][13][j], ob * dG_ddely * ddely_dy);
+				}
 			}
 		}
 		__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
@@ -2132,7 +2175,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 			if ((a = s_acc[wave][5][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id, a);
 			if ((a = s_acc[wave][6][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 1, a);
 			if ((a = s_acc[wave][7][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 2, a);
-			if ((a = s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
+			if constexpr (PAIR)
+			{
+				if ((a = s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id, a);
+				if ((a = s_acc[wave][9][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 1, a);
+				if ((a = s_acc[wave][10][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 2, a);
+				if ((a = s_acc[wave][12][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id, a);
+				if ((a = s_acc[wave][13][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id + 1, a);
+			}
+			if ((a = s_acc[wave][5 + NCH][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
 		}
 	}
 }
@@ -2553,7 +2604,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		// gradients: sum u per splat in the tile kernel, Jacobian chain once per Gaussian; tiles that do not fit the LDS
 		// index are redone (u only) by the scan kernel.  The flag array borrows tile_fill, which is dead after binning.
 		uint8_t* fallback = (uint8_t*)p.tile_fill;
-		hipLaunchKernelGGL(k_backward_lin_tile, dim3(p.T), block, 0, s, p, b, fallback);
+		hipLaunchKernelGGL((k_backward_lin_tile<false>), dim3(p.T), block, 0, s, p, b, fallback);
 		if ((rc = fr_check_launch("k_backward_lin_tile"))) return rc;
 		b.only_flagged = fallback;
 		b.u_only = 1;
@@ -2650,16 +2701,19 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity;
 	b.dL_dmean3D = dL_dmeans3D; b.dL_dcov3D = dL_dcov3D; b.dL_dscale = dL_dscales; b.dL_drot = dL_drotations;
 	b.dL_dmean2D_b = nullptr;
-	// one tile pass per image: both add into dL_dconic / dL_dopacity, each keeps its own screen-space and colour gradients
+	// one tile pass for both images (shared transmittance pass, lists and conic / opacity sums)
+	b.dL_dpix = dL_dout_color; b.colors = g->colors_precomp; b.dL_dmean2D = dL_dmeans2D; b.dL_dcolors = dL_dcolors;
+	b.dL_dpix2 = dL_dout_features; b.colors2 = features; b.dL_dmean2D_2 = dL_dmeans2D_features; b.dL_dcolors2 = dL_dfeatures;
+	b.only_flagged = nullptr; b.u_only = 0;
+	hipLaunchKernelGGL((k_backward_lin_tile<true>), dim3(p.T), block, 0, s, p, b, fallback);
+	if ((rc = fr_check_launch("k_backward_lin_tile<pair>"))) return rc;
+	// tiles whose lists do not fit the LDS index: the scan kernel, once per image
 	for (int pass = 0; pass < 2; pass++)
 	{
 		b.dL_dpix = pass ? dL_dout_features : dL_dout_color;
 		b.colors = pass ? features : g->colors_precomp;
 		b.dL_dmean2D = pass ? dL_dmeans2D_features : dL_dmeans2D;
 		b.dL_dcolors = pass ? dL_dfeatures : dL_dcolors;
-		b.only_flagged = nullptr; b.u_only = 0;
-		hipLaunchKernelGGL(k_backward_lin_tile, dim3(p.T), block, 0, s, p, b, fallback);
-		if ((rc = fr_check_launch("k_backward_lin_tile"))) return rc;
 		b.only_flagged = fallback; b.u_only = 1;
 		if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
 		else hipLaunchKernelGGL((k_backward_tile<false, false>), grid, block, 0, s, p, b);

@@ -280,3 +280,36 @@ def test_fused_rgb_depth_silhouette_pair(gpu, oracle):
     with pytest.raises(Exception):
         Renderer(raster_settings=cam, backward_power=2).forward_pair(rv["means3D"], rv["means2D"], rv["opacities"], rv["colors_precomp"],
                                                                     dv["colors_precomp"], scales=rv["scales"], rotations=rv["rotations"])
+
+
+def test_fused_pair_on_a_crowded_tile(gpu):
+    """fr_backward_pair where one tile holds ~9000 splats: the per-strip lists overflow the LDS index, the tile is flagged and
+    redone by the scan kernel once per image -- same gradients as two separate backwards."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    W, H, sc, w2c = _scene("crowded_tile")
+    cam = setup_camera(W, H, intrinsics(W, H), w2c, device=gpu)
+    P = sc["means3D"].shape[0]
+    g = torch.Generator().manual_seed(31)
+    feats0 = torch.rand((P, 3), generator=g)
+    w_a, w_b = torch.randn((3, H, W), generator=g).to(gpu), torch.randn((3, H, W), generator=g).to(gpu)
+
+    def leaves():
+        d = dict(means3D=to_dev(sc["means3D"], gpu), opacities=to_dev(sc["opacities"].reshape(-1, 1), gpu), scales=to_dev(sc["scales"], gpu),
+                 rotations=to_dev(sc["rotations"], gpu), colors=to_dev(sc["colors"], gpu), feats=feats0.clone().to(gpu))
+        return {k: v.requires_grad_(True) for k, v in d.items()}
+    a = leaves()
+    m2a = torch.zeros_like(a["means3D"], requires_grad=True)
+    im_a, rad_a, _ = Renderer(raster_settings=cam)(a["means3D"], m2a, a["opacities"], colors_precomp=a["colors"], scales=a["scales"], rotations=a["rotations"])
+    ft_a, _, _ = Renderer(raster_settings=cam)(a["means3D"], torch.zeros_like(a["means3D"], requires_grad=True), a["opacities"],
+                                                colors_precomp=a["feats"], scales=a["scales"], rotations=a["rotations"])
+    ((im_a * w_a).sum() + (ft_a * w_b).sum()).backward()
+    b = leaves()
+    m2b = torch.zeros_like(b["means3D"], requires_grad=True)
+    im_b, rad_b, _, ft_b = Renderer(raster_settings=cam).forward_pair(b["means3D"], m2b, b["opacities"], b["colors"], b["feats"],
+                                                                      scales=b["scales"], rotations=b["rotations"])
+    ((im_b * w_a).sum() + (ft_b * w_b).sum()).backward()
+    assert torch.equal(im_a, im_b) and torch.equal(ft_a, ft_b)
+    for k in a:
+        assert_close(b[k].grad.cpu().numpy(), a[k].grad.cpu().numpy(), 2e-4, f"crowded pair d/d{k}", atol_frac=1e-6)
+    assert_close(m2b.grad.cpu().numpy(), m2a.grad.cpu().numpy(), 2e-4, "crowded pair means2D.grad", atol_frac=1e-6)
