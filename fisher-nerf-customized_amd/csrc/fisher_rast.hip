@@ -772,16 +772,19 @@ __device__ __forceinline__ bool fr_pair_alpha(float xyx, float xyy, float pfx, f
 	return true;
 }
 
+// NCH = 6: a second [P,3] feature array composited in the same pass (fr_forward_pair).
+template <int NCH>
 __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const float* __restrict__ feat, int feat_view_stride,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               float* __restrict__ out_color, float* __restrict__ out_depth)
+                                                               float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                               const float* __restrict__ feat2, float* __restrict__ out_color2)
 {
 	if (p.status[1]) return;
 	__shared__ fr_f2 s_xy[FR_BATCH];
 	__shared__ fr_f4 s_co[FR_BATCH];
 	__shared__ float s_thr[FR_BATCH];
 	__shared__ float s_depth[FR_BATCH];
-	__shared__ float s_rgb[3][FR_BATCH];
+	__shared__ float s_rgb[NCH][FR_BATCH];
 
 	const int tid = threadIdx.x;
 	const int v = blockIdx.y;
@@ -799,7 +802,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
 	bool done = !inside;
 	float T = 1.0f;
 	uint32_t contributor = 0, last_contributor = 0;
-	float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+	float C[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) C[c] = 0.f;
 	float D = 15.0f;
 
 	for (uint32_t base = 0; base < n; base += FR_BATCH)
@@ -819,6 +824,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
 			s_thr[tid] = fr_power_threshold(co.w);
 			s_depth[tid] = fr_as_f32((uint32_t)(key >> 32));
 			s_rgb[0][tid] = fv[3 * (size_t)id]; s_rgb[1][tid] = fv[3 * (size_t)id + 1]; s_rgb[2][tid] = fv[3 * (size_t)id + 2];
+			if constexpr (NCH == 6)
+			{
+				s_rgb[3][tid] = feat2[3 * (size_t)id]; s_rgb[4][tid] = feat2[3 * (size_t)id + 1]; s_rgb[5][tid] = feat2[3 * (size_t)id + 2];
+			}
 		}
 		__syncthreads();
 		const int m = (int)min((uint32_t)FR_BATCH, n - base);
@@ -836,9 +845,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
 				done = true;
 				continue;
 			}
-			C0 += s_rgb[0][j] * alpha * T;
-			C1 += s_rgb[1][j] * alpha * T;
-			C2 += s_rgb[2][j] * alpha * T;
+#pragma unroll
+			for (int c = 0; c < NCH; c++) C[c] += s_rgb[c][j] * alpha * T;
 			if (T > 0.5f && test_T < 0.5f) D = s_depth[j];
 			T = test_T;
 			last_contributor = contributor;
@@ -852,9 +860,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
 		n_contrib[v * HW + pix] = last_contributor;
 		if (out_color)
 		{
-			out_color[(v * 3 + 0) * HW + pix] = C0 + T * p.bg[0];
-			out_color[(v * 3 + 1) * HW + pix] = C1 + T * p.bg[1];
-			out_color[(v * 3 + 2) * HW + pix] = C2 + T * p.bg[2];
+			out_color[(v * 3 + 0) * HW + pix] = C[0] + T * p.bg[0];
+			out_color[(v * 3 + 1) * HW + pix] = C[1] + T * p.bg[1];
+			out_color[(v * 3 + 2) * HW + pix] = C[2] + T * p.bg[2];
+		}
+		if constexpr (NCH == 6)
+		{
+			out_color2[(v * 3 + 0) * HW + pix] = C[3] + T * p.bg[0];
+			out_color2[(v * 3 + 1) * HW + pix] = C[4] + T * p.bg[1];
+			out_color2[(v * 3 + 2) * HW + pix] = C[5] + T * p.bg[2];
 		}
 		if (out_depth) out_depth[v * HW + pix] = D;
 	}
@@ -2522,9 +2536,9 @@ static void fr_carve_single(FrParams& p, const FrLayout& L, char* geom, char* bi
 	p.keys = (uint64_t*)(bin + L.keys);
 }
 
-extern "C" int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,
-                          void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
-                          float* out_color, float* out_depth, int32_t* radii, int32_t* status, fr_stream_t stream)
+static int fr_forward_impl(const fr_raster_cfg* cfg, const fr_gaussians* g, const float* features2,
+                           void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
+                           float* out_color, float* out_features2, float* out_depth, int32_t* radii, int32_t* status, fr_stream_t stream)
 {
 	int rc = fr_validate(cfg, g, "fr_forward");
 	if (rc) return rc;
@@ -2535,6 +2549,7 @@ extern "C" int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	{
 		// rasterize_points.cu:67-81: outputs stay zero, nothing is launched
 		(void)hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
+		if (out_features2) (void)hipMemsetAsync(out_features2, 0, (size_t)3 * W * H * 4, s);
 		(void)hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
 		(void)hipMemsetAsync(status, 0, 16, s);
 		return FR_OK;
@@ -2548,11 +2563,33 @@ extern "C" int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	p.key_capacity = binning_capacity;
 	if ((rc = fr_bin_pipeline(p, g, s))) return rc;
 	const float* feat = g->colors_precomp ? g->colors_precomp : p.rgb;
-	hipLaunchKernelGGL(k_render_forward, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0,
-	                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_color, out_depth);
+	if (features2)
+		hipLaunchKernelGGL((k_render_forward<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0,
+		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_color, out_depth,
+		                   features2, out_features2);
+	else
+		hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0,
+		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_color, out_depth,
+		                   (const float*)nullptr, (float*)nullptr);
 	if ((rc = fr_check_launch("k_render_forward"))) return rc;
 	(void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
 	return FR_OK;
+}
+
+extern "C" int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,
+                          void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
+                          float* out_color, float* out_depth, int32_t* radii, int32_t* status, fr_stream_t stream)
+{
+	return fr_forward_impl(cfg, g, nullptr, geom_ws, binning_ws, binning_capacity, image_ws, out_color, nullptr, out_depth, radii, status, stream);
+}
+
+extern "C" int fr_forward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, const float* features,
+                               void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
+                               float* out_color, float* out_features, float* out_depth, int32_t* radii, int32_t* status,
+                               fr_stream_t stream)
+{
+	if (!features || !out_features) return fr_fail(FR_EINVAL, "fr_forward_pair: null features / out_features");
+	return fr_forward_impl(cfg, g, features, geom_ws, binning_ws, binning_capacity, image_ws, out_color, out_features, out_depth, radii, status, stream);
 }
 
 extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
@@ -2655,8 +2692,9 @@ extern "C" int fr_forward_features(const fr_raster_cfg* cfg, const float* featur
 	FrParams p;
 	fr_fill_params(p, cfg, &g0, 1);
 	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
-	hipLaunchKernelGGL(k_render_forward, dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
-	                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr);
+	hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
+	                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr,
+	                   (const float*)nullptr, (float*)nullptr);
 	return fr_check_launch("k_render_forward(features)");
 }
 

@@ -25,6 +25,15 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 
 # ---- not in the reference's pybind module: the second feature image on shared geometry (include/fisher_rast.h) ----
+def rasterize_gaussians_pair(background, means3D, colors, features, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos, prefiltered):
+    """(num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, feature_image)"""
+    import torch
+    return _ops.rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, torch.Tensor([]),
+                                  degree, campos, prefiltered, features=features)
+
+
 def rasterize_features(features, raster_cfg_args, geomBuffer, binningBuffer, imageBuffer):
     return _ops.rasterize_forward_features(features, raster_cfg_args, geomBuffer, binningBuffer, imageBuffer)
 

@@ -80,14 +80,10 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
     def forward(ctx, means3D, means2D, means2D_features, colors_precomp, features, opacities, scales, rotations,
                 cov3Ds_precomp, raster_settings):
         rs = raster_settings
-        empty = torch.Tensor([])
-        num_rendered, color, radii, geom, binning, img, depth = _C.rasterize_gaussians(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, empty,
+        num_rendered, color, radii, geom, binning, img, depth, feat_img = _C.rasterize_gaussians_pair(
+            rs.bg, means3D, colors_precomp, features, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
             rs.sh_degree, rs.campos, rs.prefiltered)
-        feat_img = _C.rasterize_features(features, (int(means3D.shape[0]), rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy,
-                                                    rs.scale_modifier, rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos),
-                                         geom, binning, img)
         ctx.raster_settings = rs
         ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii, depth)

@@ -92,7 +92,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                       viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                      prefiltered):
+                      prefiltered, features=None):
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-115): returns
     (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer, depth[1,H,W])."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -110,6 +110,10 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
 
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    # `features` (not in the reference's argument list): a second [P,3] array composited in the same pass (fr_forward_pair);
+    # its image is appended to the returned tuple
+    feats = _prep(features, dev) if features is not None else None
+    out_feat = torch.empty((3, H, W), dtype=torch.float32, device=dev) if features is not None else None
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
     status = torch.zeros((4,), dtype=torch.int32, device=dev)
     cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, prefiltered, bg, view, proj, cpos)
@@ -123,9 +127,14 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
             geom = torch.empty((gb,), dtype=torch.uint8, device=dev)
             binning = torch.empty((bb,), dtype=torch.uint8, device=dev)
             img = torch.empty((ib,), dtype=torch.uint8, device=dev)
-            _lib.check(lib.fr_forward(ctypes.byref(cfg), ctypes.byref(g), geom.data_ptr(), binning.data_ptr(), capacity,
-                                      img.data_ptr(), _ptr(out_color), _ptr(out_depth), radii.data_ptr(),
-                                      status.data_ptr(), _stream(dev)), "fr_forward")
+            if features is not None:
+                _lib.check(lib.fr_forward_pair(ctypes.byref(cfg), ctypes.byref(g), _ptr(feats), geom.data_ptr(), binning.data_ptr(),
+                                               capacity, img.data_ptr(), _ptr(out_color), _ptr(out_feat), _ptr(out_depth),
+                                               radii.data_ptr(), status.data_ptr(), _stream(dev)), "fr_forward_pair")
+            else:
+                _lib.check(lib.fr_forward(ctypes.byref(cfg), ctypes.byref(g), geom.data_ptr(), binning.data_ptr(), capacity,
+                                          img.data_ptr(), _ptr(out_color), _ptr(out_depth), radii.data_ptr(),
+                                          status.data_ptr(), _stream(dev)), "fr_forward")
             # same host synchronisation as the reference (rasterizer_impl.cu:282: cudaMemcpy of num_rendered)
             st = status.cpu()
             num_rendered = int(st[0])
@@ -133,6 +142,8 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
                 break
             capacity = int(num_rendered * 1.25) + 1024
     _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(num_rendered * 1.25) + 1024)
+    if features is not None:
+        return num_rendered, out_color, radii, geom, binning, img, out_depth, out_feat
     return num_rendered, out_color, radii, geom, binning, img, out_depth
 
 

@@ -130,6 +130,11 @@ int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* 
  * (grad_power 1): one tile pass per image, the per-Gaussian Jacobian chain once.  dL_dmeans2D receives the colour image's
  * screen-space gradient only -- the statistic the densifier reads (gaussian.py:207) -- dL_dmeans2D_features the other
  * image's; every other output is the sum over both images, except dL_dcolors / dL_dfeatures. */
+/* fr_forward with a second feature array composited in the same pass: out_features [3,H,W] */
+int fr_forward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, const float* features,
+                    void* geom_ws, void* binning_ws, int64_t binning_capacity, void* image_ws,
+                    float* out_color, float* out_features, float* out_depth, int32_t* radii, int32_t* status,
+                    fr_stream_t stream);
 int fr_forward_features(const fr_raster_cfg* cfg, const float* features,
                         const void* geom_ws, const void* binning_ws, void* image_ws,
                         float* out_features, fr_stream_t stream);

@@ -56,9 +56,9 @@ def two_renders():
 
 
 def fused_pair():
-    R, color, radii, geom, binning, img, depth = ops.rasterize_forward(cam.bg, tp, act["rgb_colors"], act["opacities"], act["scales"], act["rotations"], 1.0, e,
-                                                                   cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, cam.campos, False)
-    fimg = ops.rasterize_forward_features(feats, cfg_args, geom, binning, img)
+    R, color, radii, geom, binning, img, depth, fimg = ops.rasterize_forward(cam.bg, tp, act["rgb_colors"], act["opacities"], act["scales"], act["rotations"], 1.0, e,
+                                                                         cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, cam.campos, False,
+                                                                         features=feats)
     return ops.rasterize_backward_pair(cam.bg, tp, radii, act["rgb_colors"], feats, act["scales"], act["rotations"], 1.0, e, cam.viewmatrix,
                                        cam.projmatrix, cam.tanfovx, cam.tanfovy, dL, dL2, cam.campos, geom, binning, img)
 
