@@ -124,3 +124,38 @@ def test_bad_arguments_are_reported(gpu):
     assert lib.fr_occ_workspace_bytes(ctypes.byref(cfg)) == 0
     assert lib.fr_occ_erode(ctypes.byref(cfg), 1, 2, 3, None) == _lib.FR_EINVAL
     assert b"fr_occ_cfg" in lib.fr_last_error()
+
+
+def test_scene_bounds_give_a_non_square_map(gpu):
+    """AstarPlanner.init with scene_bounds (astar.py:76-86): grid from the bounds, map centre off the origin; update, free space
+    and frontiers on a 281 x 201 map against the CPU restatement."""
+    from fisher_rast import synthetic
+    from oracle.occupancy_frontier import OccupancyMap, room_depth
+    from planning import AstarPlanner
+    W, H = 96, 80
+    K = synthetic.intrinsics(W, H)
+    pl = AstarPlanner(device=gpu, cell_size=0.05, frontier_select_method="closest")
+    lower, upper = np.array([-6.0, -1.5, -4.0]), np.array([8.0, 1.5, 6.0])
+    pl.init(torch.eye(4), torch.from_numpy(np.asarray(K, dtype=np.float32)), scene_bounds=(lower, upper))
+    gw, gh = int(pl.grid_dim[0]), int(pl.grid_dim[1])
+    assert (gw, gh) == (281, 201) and tuple(pl.occ_map.shape) == (3, gh, gw)
+    mc = pl.map_center.cpu().numpy()
+    assert np.allclose(mc, [1.0, 1.0])
+    om = OccupancyMap(K, grid_dim=(gw, gh), cell_size=0.05, map_center=(float(np.float32(mc[0])), float(np.float32(mc[1]))),
+                      height_range=(pl.height_lower, pl.height_upper), pcd_far_distance=pl.pcd_far_distance)
+    cz, cx = int(pl.cam_pos[0]), int(pl.cam_pos[1])
+    om.occ_map[2, cz - 1:cz + 2, cx - 1:cx + 2] = 2.0
+    assert np.array_equal(pl.occ_map.cpu().numpy(), om.occ_map)
+    poses = synthetic.candidate_poses(5, 305).numpy().astype(np.float32)
+    for t, p in enumerate(poses):
+        d = room_depth(p, W, H, K)
+        pl.update_occ_map(d, torch.from_numpy(p).to(gpu), t)
+        om.update_occ_map(d, p)
+        assert np.array_equal(pl.cam_pos, om.cam_pos)
+        assert np.array_equal(pl.occ_map.cpu().numpy(), om.occ_map), t
+    det = {}
+    want_pts, want_free = om.build_frontiers(None, method="closest", details=det)
+    got_pts, got_free = pl.build_frontiers(None)
+    assert np.array_equal(got_free, want_free) and want_free.sum() > 200
+    assert np.array_equal(pl.frontier, det["frontier"]) and np.array_equal(pl.target_frontier, det["target"])
+    assert got_pts.shape == (1, 2)
