@@ -87,6 +87,26 @@ def gpu_occupancy_frontier(dev, W, H, seed, n_frames=4, n_gaussians=200_000):
                 kernels="fr_occ_update / fr_occ_freespace / fr_occ_frontiers (csrc/fisher_occ.hip), wall time incl. host glue")
 
 
+def api_pose_eval_latency(dev, act_raw, W, H, seed, V):
+    """End-to-end latency of the drop-in call `GaussianSLAM.pose_eval(poses)` (gaussian.py:1354-1375): activation of the raw
+    parameters, H_train over 16 keyframes, V candidate scores, scores on the host -- what the planner waits for."""
+    import models.gaussian_slam as mgs
+    from fisher_rast import synthetic
+    slam = mgs.GaussianSLAM(params={k: v.to(dev) for k, v in act_raw.items()}, intrinsics=synthetic.intrinsics(W, H), width=W, height=H, device=dev)
+    for kf in synthetic.invert_rigid(synthetic.candidate_poses(16, seed + 100)):
+        slam.add_keyframe(kf.to(dev))
+    poses = [p.to(dev) for p in synthetic.candidate_poses(V, seed)]
+    slam.pose_eval(poses)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        scores, _ = slam.pose_eval(poses)
+    torch.cuda.synchronize()
+    return dict(ms_per_call=1e3 * (time.perf_counter() - t0) / reps, views=V, keyframes=16,
+                what="GaussianSLAM.pose_eval(poses): H_train over the keyframes + all candidate scores, result on the host")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +255,8 @@ def main():
             from oracle import occupancy_frontier
             out["cpu_occupancy_frontier"] = occupancy_frontier.time_baseline(n_frames=4, W=W, H=H, seed=seed)
             out["gpu_occupancy_frontier"] = gpu_occupancy_frontier(dev, W, H, seed)
+            if C == 4:
+                out["api_pose_eval"] = api_pose_eval_latency(dev, synthetic.room_shell(P, seed), W, H, seed, V)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
