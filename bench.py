@@ -126,11 +126,19 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    # FR_BENCH_BACKEND=gloo with FR_BENCH_ONE_DEVICE=1 rehearses the N > 1 control flow on a single GPU (all ranks on cuda:0,
+    # collectives through the host); the measured configuration is always nccl (RCCL), one rank per GPU
+    backend = os.environ.get("FR_BENCH_BACKEND", "nccl")
+    if os.environ.get("FR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
