@@ -68,6 +68,18 @@ def test_occupancy_queries_and_validation_without_gpu(lib):
     assert lib.fr_occ_cells_of(ctypes.byref(cfg), None, 0, None, None) == 0                       # empty input is fine
 
 
+def test_pair_entry_points_validate_without_gpu(lib):
+    from fisher_rast._lib import RasterCfg, Gaussians
+    cfg, g = RasterCfg(), Gaussians()
+    cfg.P, cfg.image_width, cfg.image_height = 10, 32, 32
+    assert lib.fr_forward_pair(ctypes.byref(cfg), ctypes.byref(g), None, None, None, 0, None, None, None, None, None, None, None) == 1
+    assert b"fr_forward_pair" in lib.fr_last_error()
+    assert lib.fr_forward_features(ctypes.byref(cfg), None, None, None, None, None, None) == 1
+    assert b"fr_forward_features" in lib.fr_last_error()
+    args = [ctypes.byref(cfg), ctypes.byref(g)] + [None] * 18
+    assert lib.fr_backward_pair(*args) == 1
+
+
 def test_argument_validation_without_gpu(lib):
     from fisher_rast._lib import RasterCfg, Gaussians, FisherCfg
     cfg, g, fc = RasterCfg(), Gaussians(), FisherCfg()
