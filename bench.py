@@ -234,6 +234,10 @@ def main():
                         valu = {"insts_per_launch": pm["SQ_INSTS_VALU"], "simds": 1024, "clock_ghz": 2.4,
                                 "issue_frac": pm["SQ_INSTS_VALU"] * 4 / (1024 * kern_ms * 1e-3 * 2.4e9),
                                 "source": "profiles/pmc_k_fisher_tile_v2.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+                        if pm.get("contributing_pairs_per_launch"):
+                            # the pair-proportional work next to the GB/s (no atomics on the scoring path)
+                            valu["pairs_per_s"] = pm["contributing_pairs_per_launch"] / (kern_ms * 1e-3)
+                            valu["wave_insts_per_pair"] = pm["SQ_INSTS_VALU"] / pm["contributing_pairs_per_launch"]
                         if pm.get("SQ_ACTIVE_INST_VALU") and pm.get("SQ_BUSY_CYCLES"):
                             # clock-independent: VALU-active quad-cycles per SIMD over the kernel's busy cycles
                             # (SQ_BUSY_CYCLES is summed over the 32 shader engines; SQ_ACTIVE_INST_* count 4-cycle quanta)

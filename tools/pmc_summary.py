@@ -20,5 +20,12 @@ for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "S
           "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"):
     if k in m: out[k] = m[k]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# loop statistics of the same launch (tools/loopstats.py with a -DFR_LOOPSTATS build) are kept across refreshes
+try:
+    old = json.load(open(os.path.join(root, "profiles", "pmc_k_fisher_tile_v2.json")))
+    for k in ("contributing_pairs_per_launch", "pass1_iterations_per_launch", "walk_steps_per_launch", "loop_stats_note"):
+        if k in old: out[k] = old[k]
+except Exception:
+    pass
 json.dump(out, open(os.path.join(root, "profiles", "pmc_k_fisher_tile_v2.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
