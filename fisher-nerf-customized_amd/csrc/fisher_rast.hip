@@ -3063,40 +3063,84 @@ __device__ __forceinline__ void fr_knn_update(float px, float py, float pz, floa
 		if (best[j] > dist) { float t = best[j]; best[j] = dist; dist = t; }
 }
 
-__global__ __launch_bounds__(FR_THREADS) void k_knn_search(int P, const float* __restrict__ sorted, const uint64_t* __restrict__ keys,
-                                                           const float* __restrict__ boxes, int nb, float* __restrict__ out)
+// AABBs of the 64-point sub-boxes (16 per 1024-point box): one wave per sub-box
+#define FR_KNN_SUB 64
+__global__ __launch_bounds__(FR_THREADS) void k_knn_subboxes(int P, const float* __restrict__ sorted, float* __restrict__ sboxes)
 {
-	const int t = blockIdx.x * FR_THREADS + threadIdx.x;
-	if (t >= P) return;
-	const float px = sorted[3 * (size_t)t], py = sorted[3 * (size_t)t + 1], pz = sorted[3 * (size_t)t + 2];
-	float best[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f };
-	for (int s = max(0, t - 3); s <= min(P - 1, t + 3); s++)
+	const int sb = (int)((blockIdx.x * FR_THREADS + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+	if (sb * FR_KNN_SUB >= P) return;
+	const int t = sb * FR_KNN_SUB + lane;
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	if (t < P)
 	{
-		if (s == t) continue;
+#pragma unroll
+		for (int a = 0; a < 3; a++) { lo[a] = sorted[3 * (size_t)t + a]; hi[a] = lo[a]; }
+	}
+#pragma unroll
+	for (int a = 0; a < 3; a++)
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+	if (lane == 0)
+	{
+#pragma unroll
+		for (int a = 0; a < 3; a++) { sboxes[6 * (size_t)sb + a] = lo[a]; sboxes[6 * (size_t)sb + 3 + a] = hi[a]; }
+	}
+}
+
+__device__ __forceinline__ float fr_knn_box_dist2(float px, float py, float pz, const float* __restrict__ bx)
+{
+	float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+	if (px < bx[0] || px > bx[3]) ddx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
+	if (py < bx[1] || py > bx[4]) ddy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
+	if (pz < bx[2] || pz > bx[5]) ddz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
+	return ddx * ddx + ddy * ddy + ddz * ddz;
+}
+
+// Wave-cooperative exact search.  The 64 query points of a wave are consecutive on the Morton curve, i.e. close in space, so
+// the wave walks the box hierarchy together: a box (then a 64-point sub-box) is opened when ANY lane can still improve its
+// third-best distance there, and every lane then tests the same candidate -- the loop counters, box bounds and candidate
+// coordinates are wave-uniform (scalar loads), with no divergence.  A lane sees a superset of the candidates its own
+// pruning rule admits, so its three smallest distances are exactly those of the brute-force search.
+__global__ __launch_bounds__(FR_THREADS) void k_knn_search(int P, const float* __restrict__ sorted, const uint64_t* __restrict__ keys,
+                                                           const float* __restrict__ boxes, int nb, const float* __restrict__ sboxes,
+                                                           int nsb, float* __restrict__ out)
+{
+	const int lane = threadIdx.x & 63;
+	const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FR_THREADS + (threadIdx.x & ~63u)));
+	if (wbase >= P) return;
+	const int t = wbase + lane;
+	const bool live = t < P;
+	const int tq = live ? t : wbase;
+	const float px = sorted[3 * (size_t)tq], py = sorted[3 * (size_t)tq + 1], pz = sorted[3 * (size_t)tq + 2];
+	float best[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f };
+	for (int s = max(0, tq - 3); s <= min(P - 1, tq + 3); s++)
+	{
+		if (s == tq) continue;
 		fr_knn_update(px, py, pz, sorted[3 * (size_t)s], sorted[3 * (size_t)s + 1], sorted[3 * (size_t)s + 2], best);
 	}
 	const float reject = best[2];
 	best[0] = best[1] = best[2] = 3.402823466e+38f;
 	for (int b = 0; b < nb; b++)
 	{
-		const float* bx = boxes + 6 * (size_t)b;
-		float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-		if (px < bx[0] || px > bx[3]) ddx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
-		if (py < bx[1] || py > bx[4]) ddy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
-		if (pz < bx[2] || pz > bx[5]) ddz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
-		const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
-		if (dist > reject || dist > best[2]) continue;
-		const int end = min(P, (b + 1) * FR_KNN_BOX);
-		for (int s = b * FR_KNN_BOX; s < end; s++)
+		const float d1 = fr_knn_box_dist2(px, py, pz, boxes + 6 * (size_t)b);
+		if (!fr_any(live && !(d1 > reject || d1 > best[2]))) continue;
+		const int sb1 = min(nsb, (b + 1) * (FR_KNN_BOX / FR_KNN_SUB));
+		for (int sb = b * (FR_KNN_BOX / FR_KNN_SUB); sb < sb1; sb++)
 		{
-			if (s == t) continue;
-			fr_knn_update(px, py, pz, sorted[3 * (size_t)s], sorted[3 * (size_t)s + 1], sorted[3 * (size_t)s + 2], best);
+			const float d2 = fr_knn_box_dist2(px, py, pz, sboxes + 6 * (size_t)sb);
+			if (!fr_any(live && !(d2 > reject || d2 > best[2]))) continue;
+			const int end = min(P, (sb + 1) * FR_KNN_SUB);
+			for (int s = sb * FR_KNN_SUB; s < end; s++)
+			{
+				const float qx = sorted[3 * (size_t)s], qy = sorted[3 * (size_t)s + 1], qz = sorted[3 * (size_t)s + 2];
+				if (s != tq) fr_knn_update(px, py, pz, qx, qy, qz, best);
+			}
 		}
 	}
-	out[(uint32_t)keys[t]] = (best[0] + best[1] + best[2]) / 3.0f;
+	if (live) out[(uint32_t)keys[t]] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
-struct FrKnnLayout { size_t keys, sorted, boxes, mm, total; };
+struct FrKnnLayout { size_t keys, sorted, boxes, sboxes, mm, total; };
 static FrKnnLayout fr_knn_layout(int64_t P)
 {
 	FrKnnLayout L;
@@ -3105,6 +3149,7 @@ static FrKnnLayout fr_knn_layout(int64_t P)
 	L.keys = o; o = fr_align(o + (size_t)P * 8);
 	L.sorted = o; o = fr_align(o + (size_t)P * 12);
 	L.boxes = o; o = fr_align(o + (size_t)nb * 24);
+	L.sboxes = o; o = fr_align(o + (size_t)((P + FR_KNN_SUB - 1) / FR_KNN_SUB) * 24);
 	L.mm = o; o = fr_align(o + 32);
 	L.total = o;
 	return L;
@@ -3157,7 +3202,10 @@ extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* wo
 	hipLaunchKernelGGL(k_knn_gather, dim3(nblk), dim3(FR_THREADS), 0, s, P, points, keys, sorted);
 	const int nb = (P + FR_KNN_BOX - 1) / FR_KNN_BOX;
 	hipLaunchKernelGGL(k_knn_boxes, dim3(nb), dim3(FR_THREADS), 0, s, P, sorted, boxes);
-	hipLaunchKernelGGL(k_knn_search, dim3(nblk), dim3(FR_THREADS), 0, s, P, sorted, keys, boxes, nb, out);
+	const int nsb = (P + FR_KNN_SUB - 1) / FR_KNN_SUB;
+	float* sboxes = (float*)(ws + L.sboxes);
+	hipLaunchKernelGGL(k_knn_subboxes, dim3((nsb * 64 + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, s, P, sorted, sboxes);
+	hipLaunchKernelGGL(k_knn_search, dim3(nblk), dim3(FR_THREADS), 0, s, P, sorted, keys, boxes, nb, sboxes, nsb, out);
 	return fr_check_launch("k_knn_search");
 }
 
