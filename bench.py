@@ -87,6 +87,21 @@ def gpu_occupancy_frontier(dev, W, H, seed, n_frames=4, n_gaussians=200_000):
                 kernels="fr_occ_update / fr_occ_freespace / fr_occ_frontiers (csrc/fisher_occ.hip), wall time incl. host glue")
 
 
+def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
+    """Device-to-device copy rate of this box, read + write bytes per second (recorded beside the nominal HBM peak)."""
+    a = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def api_pose_eval_latency(dev, act_raw, W, H, seed, V):
     """End-to-end latency of the drop-in call `GaussianSLAM.pose_eval(poses)` (gaussian.py:1354-1375): activation of the raw
     parameters, H_train over 16 keyframes, V candidate scores, scores on the host -- what the planner waits for."""
@@ -261,6 +276,8 @@ def main():
             "path": {"bytes_per_view": float(B_view), "achieved_GBps": float(B_view * views_per_s / world / 1e9),
                      "frac_of_hbm_peak": float(B_view * views_per_s / world / 1e9 / HBM_PEAK_GBS)},
         }
+        if world == 1:
+            out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
         if world == 1 and a.cpu_views > 0:
             out["cpu_baseline"] = cpu_baseline(P, W, H, seed, a.cpu_views, C)
             # the reference's CPU occupancy / frontier step (planning/astar.py), timed on the same host cores
