@@ -278,6 +278,25 @@ def main():
         }
         if world == 1:
             out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
+            if C == 4:
+                # the same workload with the 11 Fisher columns of GaussianObjectSLAM, reported next to the headline
+                sc11 = FisherScorer(cam, *(act[k].to(dev) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")),
+                                    columns=11, dL_dpix=1e-3)
+                Ht11 = torch.zeros((P, 11), dtype=torch.float32, device=dev)
+                sc11.run(kf, out_H=Ht11)
+                Hi11 = torch.reciprocal(Ht11 + 0.1)
+                sc11.run(w2c, H_inv=Hi11)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n11 = max(3, a.steps // 4)
+                for _ in range(n11):
+                    r11 = sc11.launch(w2c, H_inv=Hi11)
+                    host_scores.copy_(r11["scores"], non_blocking=True)
+                torch.cuda.synchronize()
+                d11 = (time.perf_counter() - t1) / n11
+                out["columns_11"] = {"value": V / d11, "unit": "candidate-views/s", "ms_per_step": 1e3 * d11,
+                                     "fisher_scores_per_s": V / d11 * P * 11, "steps": n11}
+                del sc11, Ht11, Hi11
         if world == 1 and a.cpu_views > 0:
             out["cpu_baseline"] = cpu_baseline(P, W, H, seed, a.cpu_views, C)
             # the reference's CPU occupancy / frontier step (planning/astar.py), timed on the same host cores
