@@ -960,6 +960,7 @@ struct FrFisherArgs {
 	float dL;                    // constant upstream gradient
 	const float* dL_img;         // or per view an upstream-gradient image [V][3][H][W] (out_H modes only), stride in floats
 	long long dL_stride;
+	float* full_out[8];          // k_fisher_tile_v2<25>: dL_dmeans3D, dL_dopacity, dL_dscales, dL_drotations, dL_dcolors, dL_dmeans2D, dL_dcov3D, dL_dconic
 	const float* H_inv; long long hinv_stride;
 	float* out_H; long long outH_stride;
 	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 // H_inv[C] } = 16 floats (64 B, one cache line) at C = 4, 32 floats at C = 11.  k_build_records then needs two gathers
 // per tile instance (this record and the 32-byte FrSplat) instead of six.  With per-view H_inv the weights are
 // gathered separately.
-template <int C> struct FrPackSize { static constexpr int value = (C == 11) ? 32 : 16; };
+template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
 
 template <int C>
 __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed)
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 #pragma unroll
 	for (int k = 0; k < 3; k++) b[9 + k] = p.colors[3 * (size_t)i + k];
 	int o = 12;
-	if constexpr (C == 11)
+	if constexpr (C >= 11)
 	{
 #pragma unroll
 		for (int k = 0; k < 3; k++) b[12 + k] = p.scales[3 * (size_t)i + k];
@@ -1236,10 +1237,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 		for (int k = 0; k < 4; k++) b[15 + k] = p.rots[4 * (size_t)i + k];
 		o = 19;
 	}
-	if (H_inv)
+	if constexpr (C <= 11)
 	{
+		if (H_inv)
+		{
 #pragma unroll
-		for (int c = 0; c < C; c++) b[o + c] = H_inv[(size_t)i * C + c];
+			for (int c = 0; c < C; c++) b[o + c] = H_inv[(size_t)i * C + c];
+		}
 	}
 	float4* dst = (float4*)(packed + (size_t)i * PS);
 #pragma unroll
@@ -1275,8 +1279,14 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 	// QFORM (score only): the weighted sum of squared leaves is a quadratic form in u',
 	//   sum_c H_inv[c] (M_c . u')^2 = u'^T Q u',  Q = sum_c H_inv[c] M_c^T M_c  (5 x 5 symmetric, 15 numbers),
 	// so the walk fetches rgb[3], Q[15], k3 instead of 51 values per entry, whatever the number of columns.
+	// C = 25 (FULL): every leaf of the rasteriser's power-2 backward (backward.cu:1095-1137) for one view -- camera-frame mean 3,
+	// opacity 1, scale 3, rotation 4, colour 3, mean2D 2, cov3D 6, conic 3 -- summed per Gaussian into the gradient tensors
+	// of fr_backward (f.full_out); the per-entry record then also carries B' = -1/2 d(dL_dcov3D)/d(dL_dconic) (18 numbers).
+	constexpr bool SR = C >= 11;
+	constexpr bool FULL = C == 25;
+	static_assert(!FULL || (HAS_OUTH && !HAS_HINV), "the all-leaves mode has no weights");
 	constexpr bool QFORM = HAS_HINV && !HAS_OUTH;
-	constexpr int KO = QFORM ? 18 : ((C == 11) ? 39 : 18);   // offset of k3 = 1/opacity^2 (times H_inv[3] when only the score is wanted)
+	constexpr int KO = QFORM ? 18 : (FULL ? 57 : (SR ? 39 : 18));   // offset of k3 = 1/opacity^2 (times H_inv[3] when only the score is wanted)
 	constexpr int HO = KO + 1;                    // offset of the H_inv columns
 	constexpr bool FOLD3 = HAS_HINV && !HAS_OUTH; // H_inv[3] folded into k3
 	constexpr int NB = QFORM ? 19 : HO + (HAS_HINV ? C : 0);
@@ -1469,7 +1479,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 			fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
 			float A[3][5];
 			float B[6][3];
-			fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, (C == 11) ? B : nullptr);
+			fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr);
 			// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
 			// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
 			float Ap[3][5];
@@ -1480,9 +1490,9 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 #pragma unroll
 				for (int c = 2; c < 5; c++) Ap[r][c] = -0.5f * A[r][c];
 			}
-			float Cp[(C == 11) ? 7 : 1][3];
+			float Cp[SR ? 7 : 1][3];
 			int go = 12;
-			if constexpr (C == 11)
+			if constexpr (SR)
 			{
 				fr_f3 sc = { gsv[12], gsv[13], gsv[14] };
 				fr_f4 qr = { gsv[15], gsv[16], gsv[17], gsv[18] };
@@ -1520,7 +1530,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 					for (int j = i; j < 5; j++)
 					{
 						float acc = hv[0] * Ap[0][i] * Ap[0][j] + hv[1] * Ap[1][i] * Ap[1][j] + hv[2] * Ap[2][i] * Ap[2][j];
-						if constexpr (C == 11)
+						if constexpr (SR)
 						{
 							if (i >= 2)
 							{
@@ -1538,12 +1548,19 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 				for (int r = 0; r < 3; r++)
 #pragma unroll
 					for (int c = 0; c < 5; c++) b[3 + r * 5 + c] = Ap[r][c];
-				if constexpr (C == 11)
+				if constexpr (SR)
 				{
 #pragma unroll
 					for (int r = 0; r < 7; r++)
 #pragma unroll
 						for (int c = 0; c < 3; c++) b[18 + r * 3 + c] = Cp[r][c];
+				}
+				if constexpr (FULL)
+				{
+#pragma unroll
+					for (int r = 0; r < 6; r++)
+#pragma unroll
+						for (int c = 0; c < 3; c++) b[39 + r * 3 + c] = -0.5f * B[r][c];
 				}
 				if constexpr (HAS_HINV)
 				{
@@ -1666,7 +1683,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 						leaf2[q] = l * l;
 					}
 					leaf2[3] = r[KO];
-					if constexpr (C == 11)
+					if constexpr (SR)
 					{
 #pragma unroll
 						for (int q = 0; q < 7; q++)
@@ -1674,6 +1691,20 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 							const float l = r[18 + q * 3 + 0] * u[2] + r[18 + q * 3 + 1] * u[3] + r[18 + q * 3 + 2] * u[4];
 							leaf2[4 + q] = l * l;
 						}
+					}
+					if constexpr (FULL)
+					{
+						// colour: dL_dcolor_c = alpha T dL_dpix_c (not a multiple of w: pre-divided by w2, which multiplies every column below)
+						const float wc = alpha * st.T, iw2 = has ? __builtin_amdgcn_rcpf(w2) : 0.f;
+						leaf2[11] = (wc * g0) * (wc * g0) * iw2; leaf2[12] = (wc * g1) * (wc * g1) * iw2; leaf2[13] = (wc * g2) * (wc * g2) * iw2;
+						leaf2[14] = (u[0] * ddelx_dx) * (u[0] * ddelx_dx); leaf2[15] = (u[1] * ddely_dy) * (u[1] * ddely_dy);
+#pragma unroll
+						for (int q = 0; q < 6; q++)
+						{
+							const float l = r[39 + q * 3 + 0] * u[2] + r[39 + q * 3 + 1] * u[3] + r[39 + q * 3 + 2] * u[4];
+							leaf2[16 + q] = l * l;
+						}
+						leaf2[22] = 0.25f * u[2] * u[2]; leaf2[23] = 0.25f * u[3] * u[3]; leaf2[24] = 0.25f * u[4] * u[4];
 					}
 					if constexpr (HAS_HINV)
 					{
@@ -1701,7 +1732,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 			__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
 			// Flush with consecutive lanes on consecutive columns of one entry: an atomic instruction then touches 64 / C rows
 			// of out_H (C contiguous floats each) instead of 64 -- the L2 sees a quarter (C = 4) of the requests.
-			float* dst = f.out_H + (size_t)v * f.outH_stride;
+			float* dst = FULL ? nullptr : f.out_H + (size_t)v * f.outH_stride;
 #pragma unroll
 			for (int i = 0; i < C; i++)
 			{
@@ -1709,7 +1740,20 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 				const int e = flat / C, c = flat - e * C;
 				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)my_id);
 				const float a = (e < m) ? s_acc[wave][c][e] : 0.f;
-				if (a != 0.f) atomicAdd(dst + (size_t)id_e * C + c, a);
+				if constexpr (FULL)
+				{
+					// column -> (gradient tensor, row stride, offset): means3D 0-2, opacity 3, scales 4-6, rotations 7-10, colours 11-13,
+					// means2D 14-15 (z unused), cov3D 16-21, conic 22-24 (entries 0, 1, 3 of the 2x2)
+					const int arr = c < 3 ? 0 : c < 4 ? 1 : c < 7 ? 2 : c < 11 ? 3 : c < 14 ? 4 : c < 16 ? 5 : c < 22 ? 6 : 7;
+					const int first = arr == 0 ? 0 : arr == 1 ? 3 : arr == 2 ? 4 : arr == 3 ? 7 : arr == 4 ? 11 : arr == 5 ? 14 : arr == 6 ? 16 : 22;
+					const int stride = arr == 1 ? 1 : (arr == 3 || arr == 7) ? 4 : arr == 6 ? 6 : 3;
+					const int off = (c == 24) ? 3 : c - first;
+					if (a != 0.f) atomicAdd(f.full_out[arr] + (size_t)id_e * stride + off, a);
+				}
+				else
+				{
+					if (a != 0.f) atomicAdd(dst + (size_t)id_e * C + c, a);
+				}
 			}
 		}
 	}
@@ -2321,7 +2365,7 @@ static inline long long fr_preprocess_blocks(long long P, long long V)
 
 struct FrLayout {
 	// geometry
-	size_t splat, cov3D, rgb, clamped, geom_bytes;
+	size_t splat, cov3D, rgb, clamped, packed, geom_bytes;
 	// image
 	size_t tile_cnt, tile_off, tile_fill, final_T, n_contrib, status, big_list, img_bytes;
 	// binning
@@ -2338,6 +2382,7 @@ static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t ma
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.rgb = o; o = fr_align(o + VP * 12);
 	L.clamped = o; o = fr_align(o + VP * 3);
+	L.packed = o; o = fr_align(o + (size_t)P * 128);     // static records of k_fisher_tile_v2<25> (power-2 backward), written by fr_backward
 	L.geom_bytes = o > 0 ? o : 256;
 	o = 0;
 	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
@@ -2658,6 +2703,27 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		else if (sh) hipLaunchKernelGGL((k_backward_finish<false, true>), gp, block, 0, s, p, b, dL_dsh);
 		else hipLaunchKernelGGL((k_backward_finish<false, false>), gp, block, 0, s, p, b, dL_dsh);
 		return fr_check_launch("k_backward_finish");
+	}
+	if (power == 2 && sr && !sh && g->colors_precomp && !g->cov3D_precomp)
+	{
+		// The diagonal Fisher proxy as the reference's own loop asks for it (gaussian.py:1536-1556: one view, autograd, power 2):
+		// the wave-private two-pass kernel of the batched scorer with all 25 leaves, the upstream gradient as a per-pixel image;
+		// tiles that do not fit its LDS index are redone by the generic kernel below.
+		float* packed = (float*)((char*)geom_ws + L.packed);
+		uint8_t* fallback = (uint8_t*)p.tile_fill;
+		FrParams pp = p;
+		pp.colors = g->colors_precomp;
+		hipLaunchKernelGGL((k_pack_static<25>), dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, pp, (const float*)nullptr, packed);
+		FrFisherArgs f;
+		memset(&f, 0, sizeof(f));
+		f.dL_img = dL_dout_color; f.dL_stride = 0;
+		f.full_out[0] = dL_dmeans3D; f.full_out[1] = dL_dopacity; f.full_out[2] = dL_dscales; f.full_out[3] = dL_drotations;
+		f.full_out[4] = dL_dcolors; f.full_out[5] = dL_dmeans2D; f.full_out[6] = dL_dcov3D; f.full_out[7] = dL_dconic;
+		hipLaunchKernelGGL((k_fisher_tile_v2<25, false, true>), dim3(p.T), block, 0, s, pp, f, (const float*)packed, fallback);
+		if ((rc = fr_check_launch("k_fisher_tile_v2<25>"))) return rc;
+		b.only_flagged = fallback;
+		hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
+		return fr_check_launch("k_backward_tile(flagged)");
 	}
 	if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
 	else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
