@@ -113,6 +113,12 @@ __device__ __forceinline__ int wave_max_i(int v)
 	return v;
 }
 
+// wave votes on the scalar unit (the __any / __all builtins go through a VGPR round trip)
+__device__ __forceinline__ bool fr_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+__device__ __forceinline__ bool fr_all(bool x) { return __builtin_amdgcn_ballot_w64(!x) == 0ull; }
+__device__ __forceinline__ float fr_readlane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_float(__builtin_amdgcn_ds_bpermute(l << 2, __float_as_int(x))); }
+
 // Hardware exponential (v_exp_f32 after one multiply, ~1 ulp of 2^x) for the SCORER only: its bar is 1e-4 on the scores, and a
 // pair whose alpha sits within an ulp of 1/255 (or a pixel whose T sits within an ulp of 1e-4) carries a weight far below
 // that.  The single-view rasteriser keeps fr_expf, whose forward outputs are bit-identical to the oracle's.
@@ -772,6 +778,11 @@ __device__ __forceinline__ bool fr_pair_alpha(float xyx, float xyy, float pfx, f
 	return true;
 }
 
+// Forward compositing (forward.cu:261-393), wave-private: a wave owns the 16x4 strip of rows 4w..4w+3, streams the tile's sorted
+// keys 64 at a time, keeps the splats whose conservative alpha footprint meets its strip (one ballot) and walks the set bits in
+// order with v_readlane broadcasts -- no LDS staging, no barrier, and a wave only evaluates the ~1/3 of the tile's splats that
+// can reach its pixels.  A skipped splat is one whose alpha is below 1/255 on every pixel of the strip, i.e. one the reference
+// skips pixel by pixel, so colour, depth, final_T and n_contrib are unchanged (bit-identical to the oracle).
 // NCH = 6: a second [P,3] feature array composited in the same pass (fr_forward_pair).
 template <int NCH>
 __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const float* __restrict__ feat, int feat_view_stride,
@@ -780,13 +791,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
                                                                const float* __restrict__ feat2, float* __restrict__ out_color2)
 {
 	if (p.status[1]) return;
-	__shared__ fr_f2 s_xy[FR_BATCH];
-	__shared__ fr_f4 s_co[FR_BATCH];
-	__shared__ float s_thr[FR_BATCH];
-	__shared__ float s_depth[FR_BATCH];
-	__shared__ float s_rgb[NCH][FR_BATCH];
-
-	const int tid = threadIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int v = blockIdx.y;
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
@@ -797,60 +803,83 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward(FrParams p, const
 	const size_t vP = (size_t)v * p.P;
 	const uint32_t n = p.tile_cnt[vt];
 	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* splat = (const float4*)(p.splat + vP);
 	const float* fv = feat + (size_t)v * feat_view_stride;
 
-	bool done = !inside;
+	unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
 	float T = 1.0f;
-	uint32_t contributor = 0, last_contributor = 0;
+	uint32_t last_contributor = 0;
 	float C[NCH];
 #pragma unroll
 	for (int c = 0; c < NCH; c++) C[c] = 0.f;
 	float D = 15.0f;
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
 
-	for (uint32_t base = 0; base < n; base += FR_BATCH)
+	uint64_t kn = ((uint32_t)lane < n) ? gk[lane] : 0ull;
+	for (uint32_t base = 0; base < n; base += 64)
 	{
-		if (__syncthreads_count(done) == FR_THREADS) break;
-		const uint32_t k = base + tid;
-		if (k < n)
-		{
-			const uint64_t key = gk[k];
-			const uint32_t id = (uint32_t)key;
-			const float4* sp = (const float4*)(p.splat + vP + id);
-			const float4 q0 = sp[0], q1 = sp[1];
-			fr_f2 xy = { q0.x, q0.y };
-			s_xy[tid] = xy;
-			const fr_f4 co = { q0.z, q0.w, q1.x, q1.y };
-			s_co[tid] = co;
-			s_thr[tid] = fr_power_threshold(co.w);
-			s_depth[tid] = fr_as_f32((uint32_t)(key >> 32));
-			s_rgb[0][tid] = fv[3 * (size_t)id]; s_rgb[1][tid] = fv[3 * (size_t)id + 1]; s_rgb[2][tid] = fv[3 * (size_t)id + 2];
-			if constexpr (NCH == 6)
-			{
-				s_rgb[3][tid] = feat2[3 * (size_t)id]; s_rgb[4][tid] = feat2[3 * (size_t)id + 1]; s_rgb[5][tid] = feat2[3 * (size_t)id + 2];
-			}
-		}
-		__syncthreads();
-		const int m = (int)min((uint32_t)FR_BATCH, n - base);
-		for (int j = 0; !done && j < m; j++)
-		{
-			contributor++;
-			const fr_f2 xy = s_xy[j];
-			const fr_f4 co = s_co[j];
-			float dx, dy, G, alpha;
-			if (!fr_pair_alpha(xy.x, xy.y, pfx, pfy, co.x, co.y, co.z, co.w, s_thr[j], dx, dy, G, alpha))
-				continue;
-			const float test_T = T * (1 - alpha);
-			if (test_T < 0.0001f)
-			{
-				done = true;
-				continue;
-			}
+		const uint64_t key = kn;
+		if (base + 64 + lane < n) kn = gk[base + 64 + lane];
+		const bool valid = base + lane < n;
+		const uint32_t id = (uint32_t)key;
+		float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+		if (valid) { q0 = splat[2 * (size_t)id]; q1 = splat[2 * (size_t)id + 1]; }
+		const uint32_t eb = __float_as_uint(q1.w);
+		const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+		const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+		const bool ov = valid && hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi) && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
+		unsigned long long todo = __ballot(ov);
+		if (todo == 0ull) continue;
+		const float thr_l = fr_power_threshold(q1.y);
+		const float dep_l = fr_as_f32((uint32_t)(key >> 32));
+		float fl[NCH];
 #pragma unroll
-			for (int c = 0; c < NCH; c++) C[c] += s_rgb[c][j] * alpha * T;
-			if (T > 0.5f && test_T < 0.5f) D = s_depth[j];
-			T = test_T;
-			last_contributor = contributor;
+		for (int c = 0; c < NCH; c++) fl[c] = 0.f;
+		if (ov)
+		{
+			fl[0] = fv[3 * (size_t)id]; fl[1] = fv[3 * (size_t)id + 1]; fl[2] = fv[3 * (size_t)id + 2];
+			if constexpr (NCH == 6) { fl[3] = feat2[3 * (size_t)id]; fl[4] = feat2[3 * (size_t)id + 1]; fl[5] = feat2[3 * (size_t)id + 2]; }
 		}
+		while (todo)
+		{
+			const int j = __builtin_ctzll(todo);
+			todo &= todo - 1ull;
+			const float x = fr_readlane_f(q0.x, j), y = fr_readlane_f(q0.y, j);
+			const float cx = fr_readlane_f(q0.z, j), cy = fr_readlane_f(q0.w, j), cz = fr_readlane_f(q1.x, j);
+			const float o = fr_readlane_f(q1.y, j), thr = fr_readlane_f(thr_l, j);
+			const float dx = x - pfx, dy = y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			// forward.cu:338-357; NaN falls through both tests as it does there
+			const unsigned long long skip_m = __builtin_amdgcn_fcmpf(power, 0.0f, 2 /* ogt */) | __builtin_amdgcn_fcmpf(power, thr, 4 /* olt */);
+			const unsigned long long pass_m = ~(skip_m | done_m);
+			if (pass_m)
+			{
+				const float G = fr_expf(power);
+				const float alpha = fminf(0.99f, o * G);
+				const unsigned long long ok_m = pass_m & ~__builtin_amdgcn_fcmpf(alpha, 1.0f / 255.0f, 4 /* olt */);
+				const float test_T = T * (1 - alpha);
+				const unsigned long long kill_m = ok_m & __builtin_amdgcn_fcmpf(test_T, 0.0001f, 4 /* olt */);
+				const unsigned long long contrib_m = ok_m & ~kill_m;
+				done_m |= kill_m;
+				if (contrib_m)
+				{
+					const bool contrib = __builtin_amdgcn_inverse_ballot_w64(contrib_m);
+#pragma unroll
+					for (int c = 0; c < NCH; c++)
+					{
+						const float fc = fr_readlane_f(fl[c], j);
+						const float add = fc * alpha * T;
+						C[c] = contrib ? C[c] + add : C[c];
+					}
+					const float dj = fr_readlane_f(dep_l, j);
+					D = (contrib && T > 0.5f && test_T < 0.5f) ? dj : D;
+					T = contrib ? test_T : T;
+					last_contributor = contrib ? (base + (uint32_t)j + 1u) : last_contributor;
+				}
+			}
+		}
+		if (done_m == ~0ull) break;
 	}
 	if (inside)
 	{
@@ -1259,11 +1288,6 @@ __device__ __forceinline__ float fr_scorer_exponent(float hcx, float ncy, float 
 	power = __builtin_fmaf(dx, t, v * dy);
 	return __builtin_fmaf(power, 1.44269504088896341f, lo);
 }
-// wave votes on the scalar unit (the __any / __all builtins go through a VGPR round trip)
-__device__ __forceinline__ bool fr_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
-__device__ __forceinline__ bool fr_all(bool x) { return __builtin_amdgcn_ballot_w64(!x) == 0ull; }
-__device__ __forceinline__ float fr_readlane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
-__device__ __forceinline__ float fr_bperm_f(float x, int l) { return __int_as_float(__builtin_amdgcn_ds_bpermute(l << 2, __float_as_int(x))); }
 
 // HAS_HINV: weighted score per view (pose_eval).  HAS_OUTH: cur_H materialised / accumulated (compute_Hessian,
 // compute_H_train): the pixel-lanes of a wave add their squared leaves into a 64-entry LDS accumulator of the chunk
