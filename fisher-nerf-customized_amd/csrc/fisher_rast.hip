@@ -1,22 +1,28 @@
 // fisher_rast.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of
 // libfisher_rast.so.  See include/fisher_rast.h for the boundary and DESIGN.md for the layout.
 //
-// Pipeline (single view: V = 1; Fisher scorer: V candidate views batched as blockIdx.y):
-//   k_cov3d            once per call      scale/quaternion -> cov3D[P][6]            (forward.cu:118-152)
-//   k_preprocess       grid (P/1024, V)   project, cull, conic, radius, tile rect, per-tile COUNT
-//                                         through an LDS histogram                   (forward.cu:155-256)
-//   k_scan_tiles       1 block            exclusive scan of the V*T tile counts -> segment offsets,
-//                                         device-side num_rendered / overflow flag   (replaces cub::InclusiveSum +
-//                                         the blocking cudaMemcpy of rasterizer_impl.cu:277-282)
-//   k_scatter_keys     grid (P/1024, V)   emit (depth_bits<<32 | gaussian) into the tile's segment
-//                                         (duplicateWithKeys, rasterizer_impl.cu:70-111)
-//   k_sort_tiles       grid (T, V)        per-tile bitonic network in LDS on the 64-bit keys: replaces the global
-//                                         cub::DeviceRadixSort (rasterizer_impl.cu:304-309).  Keys are unique, so the
-//                                         result equals the reference's stable (tile, depth) order with ties by index.
-//   k_render_forward   grid (T, V)        alpha compositing, median depth           (forward.cu:261-393)
-//   k_backward_tile    grid (T, 1)        fused backward with grad_power            (backward.cu:850-1140)
-//   k_fisher_tile      grid (T, V)        transmittance pass + backward(power=2) + sum(cur_H * H_inv) fused:
-//                                         gaussian.py:1548-1556,1367 without materialising any gradient tensor
+// Pipeline (single view: V = 1; Fisher scorer: V candidate views in one launch):
+//   k_cov3d              once per call      scale/quaternion -> cov3D[P][6]            (forward.cu:118-152)
+//   k_preprocess         (P/(256 G), V)     project, cull, conic, radius, tile rect, per-tile COUNT through an LDS histogram
+//   k_preprocess_views   (P/(256 G), V/VC)  the same for many views of one camera: near-plane compaction, dense projection,
+//                                           compact visible lists                      (forward.cu:155-256)
+//   k_scan_tiles         1 block            exclusive scan of the V*T tile counts -> segment offsets, device-side
+//                                           num_rendered / overflow flag (replaces cub::InclusiveSum + the blocking
+//                                           cudaMemcpy of rasterizer_impl.cu:277-282)
+//   k_scatter_keys/_vis  (P/(256 G), V)     emit (depth_bits<<32 | gaussian) into the tile's segment
+//                                           (duplicateWithKeys, rasterizer_impl.cu:70-111)
+//   k_sort_tiles/_mid/_big                  per-tile bitonic network in LDS on the 64-bit keys: replaces the global
+//                                           cub::DeviceRadixSort (rasterizer_impl.cu:304-309).  Keys are unique, so the
+//                                           result equals the reference's stable (tile, depth) order with ties by index.
+//   k_render_forward<3|6>  (T, V)           alpha compositing, median depth, wave-private strips (forward.cu:261-393)
+//   k_backward_lin_tile<pair> + k_backward_finish   grad_power 1 (training): per-splat sums of the screen-space gradients,
+//                                           Jacobian chain once per Gaussian           (backward.cu:850-1140, 276-583)
+//   k_backward_tile      (T, 1)             generic fused backward, any grad_power, SH colours
+//   k_fisher_tile_v2<4|11|25>  T*V          transmittance pass + backward(power=2) fused, wave-private: sum(cur_H * H_inv) per
+//                                           view (gaussian.py:1548-1556, 1367) without materialising any gradient tensor,
+//                                           or cur_H / all 25 leaves accumulated (out_H modes)
+//   k_fisher_tile        T*V                first-generation scan kernel: fallback for tiles beyond the LDS index of the above
+//   k_knn_*                                 simple-knn distCUDA2
 //
 // Wave64 mapping of a 16x16 tile: 256 threads = 4 waves, wave w owns the 16x4 pixel strip of rows 4w..4w+3, so a
 // small splat is seen by 1-2 waves and the others skip it with one ballot.
