@@ -68,24 +68,36 @@ __global__ void k_occ_mark_cam(OccUpdateArgs a, float* __restrict__ occ_map)
 __global__ __launch_bounds__(OCC_THREADS) void k_occ_bin(OccUpdateArgs a, const float* __restrict__ depth, uint32_t* __restrict__ cnt)
 {
 	const int i = blockIdx.x * OCC_THREADS + threadIdx.x;
-	if (i >= a.nx * a.ny) return;
-	const int ix = i % a.nx, iy = i / a.nx;
+	const bool live = i < a.nx * a.ny;
+	const int lane = threadIdx.x & 63;
+	const int ix = live ? i % a.nx : 0, iy = live ? i / a.nx : 0;
 	const float xg = (float)(ix * a.ds), yg = (float)(iy * a.ds);
 	const float xx = (xg - a.cx) / a.fx, yy = (yg - a.cy) / a.fy;
-	const float d = depth[(size_t)(iy * a.ds) * a.W + ix * a.ds];
+	const float d = live ? depth[(size_t)(iy * a.ds) * a.W + ix * a.ds] : 0.0f;
 	const size_t cells = (size_t)a.g.gw * a.g.gh;
 	for (int k = 0; k < a.n_samples; k++)
 	{
 		const float dz = a.fracs[k] * d;
-		if (!(dz > 0.0f && dz < a.g.far_d)) continue;
+		bool ok = live && dz > 0.0f && dz < a.g.far_d;
 		const float px = xx * dz, py = yy * dz;
 		// c2w @ (px, py, dz, 1), accumulated left to right
 		const float wx = ((a.c2w[0] * px + a.c2w[1] * py) + a.c2w[2] * dz) + a.c2w[3];
 		const float wy = ((a.c2w[4] * px + a.c2w[5] * py) + a.c2w[6] * dz) + a.c2w[7];
 		const float wz = ((a.c2w[8] * px + a.c2w[9] * py) + a.c2w[10] * dz) + a.c2w[11];
-		if (!(wy >= a.g.hlo && wy <= a.g.hhi)) continue;
+		ok = ok && wy >= a.g.hlo && wy <= a.g.hhi;
 		const int xb = occ_bin(wx, a.g.cx, a.g.cell, a.g.gw), zb = occ_bin(wz, a.g.cz, a.g.cell, a.g.gh);
-		atomicAdd(&cnt[(k == a.n_samples - 1 ? cells : 0) + (size_t)zb * a.g.gw + xb], 1u);
+		const int key = ok ? (int)((k == a.n_samples - 1 ? cells : 0) + (size_t)zb * a.g.gw + xb) : -1;
+		// The 64 pixels of a wave are neighbours in a row and their k-th samples mostly share a handful of cells (near the camera:
+		// one): aggregate equal cells with ballots and issue one atomic per distinct cell instead of one per sample.
+		unsigned long long todo = __ballot(key >= 0);
+		while (todo)
+		{
+			const int leader = __builtin_ctzll(todo);
+			const int kl = __builtin_amdgcn_readlane(key, leader);
+			const unsigned long long same = __ballot(key == kl);
+			if (lane == leader) atomicAdd(&cnt[kl], (uint32_t)__popcll(same));
+			todo &= ~same;
+		}
 	}
 }
 
@@ -242,14 +254,40 @@ __global__ __launch_bounds__(OCC_THREADS) void k_cc_flatten(OccGeom g, int* __re
                                                            double* __restrict__ dist_sum, int cam_row, int cam_col)
 {
 	const int i = blockIdx.x * OCC_THREADS + threadIdx.x;
-	if (i >= g.gw * g.gh || lab[i] < 0) return;
-	const int r = occ_find(lab, i);
-	lab[i] = r;
-	atomicAdd(&size[r], 1u);
-	if (dist_sum)
+	const int lane = threadIdx.x & 63;
+	int r = -1;
+	if (i < g.gw * g.gh && lab[i] >= 0)
+	{
+		r = occ_find(lab, i);
+		lab[i] = r;
+	}
+	double d = 0.0;
+	if (dist_sum && r >= 0)
 	{
 		const double dy = (double)(i / g.gw - cam_row), dx = (double)(i % g.gw - cam_col);
-		atomicAdd(&dist_sum[r], sqrt(dy * dy + dx * dx));
+		d = sqrt(dy * dy + dx * dx);
+	}
+	// the 64 cells of a wave are neighbours in a row and mostly belong to one or two components: one atomic per distinct
+	// component and wave instead of one per cell (all of them on the few addresses of the large components otherwise)
+	unsigned long long todo = __ballot(r >= 0);
+	while (todo)
+	{
+		const int leader = __builtin_ctzll(todo);
+		const int rl = __builtin_amdgcn_readlane(r, leader);
+		const bool mine = r == rl;
+		const unsigned long long same = __ballot(mine);
+		double sum = mine ? d : 0.0;
+		if (dist_sum)
+		{
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+		}
+		if (lane == leader)
+		{
+			atomicAdd(&size[rl], (uint32_t)__popcll(same));
+			if (dist_sum) atomicAdd(&dist_sum[rl], sum);
+		}
+		todo &= ~same;
 	}
 }
 
@@ -257,15 +295,25 @@ __global__ __launch_bounds__(OCC_THREADS) void k_cc_flatten(OccGeom g, int* __re
 // Frontier modes (only components with size > min_area): 1 largest (ties: largest id, the reversed argsort of astar.py:581),
 // 2 combined size / (mean distance + 20) with a strict ">" in label order (ties: smallest id), 3 closest mean distance
 // with a strict "<" (ties: smallest id).  out = {chosen id or -1, its size, number of qualifying components}.
-__global__ __launch_bounds__(1024) void k_cc_select(int n, const int* __restrict__ lab, const uint32_t* __restrict__ size,
-                                                   const double* __restrict__ dist_sum, int mode, uint32_t min_area, int* __restrict__ out)
+// `better(key a, id a, key b, id b)`: does a beat b under the mode's tie rule
+__device__ __forceinline__ bool occ_better(double ka, int ia, double kb, int ib, int mode)
 {
-	__shared__ double s_key[1024];
-	__shared__ int s_id[1024];
-	__shared__ int s_cnt[1024];
+	if (ia < 0) return false;
+	if (ib < 0) return true;
+	return ka > kb || (ka == kb && (mode == 1 ? ia > ib : ia < ib));
+}
+// stage 1: every workgroup scans a slice of the cells and leaves its best component in part_key / part_id / part_cnt
+#define OCC_SELECT_BLOCKS 128
+__global__ __launch_bounds__(OCC_THREADS) void k_cc_select_partial(int n, const int* __restrict__ lab, const uint32_t* __restrict__ size,
+                                                                  const double* __restrict__ dist_sum, int mode, uint32_t min_area,
+                                                                  double* __restrict__ part_key, int* __restrict__ part_id, int* __restrict__ part_cnt)
+{
+	__shared__ double s_key[OCC_THREADS];
+	__shared__ int s_id[OCC_THREADS];
+	__shared__ int s_cnt[OCC_THREADS];
 	const int tid = threadIdx.x;
 	double best = 0.0; int best_id = -1; int cnt = 0;
-	for (int i = tid; i < n; i += 1024)
+	for (int i = blockIdx.x * OCC_THREADS + tid; i < n; i += gridDim.x * OCC_THREADS)
 	{
 		if (lab[i] != i) continue;
 		const uint32_t c = size[i];
@@ -283,22 +331,40 @@ __global__ __launch_bounds__(1024) void k_cc_select(int n, const int* __restrict
 				if (mode == 2 && !(key > 0.0)) continue;
 			}
 		}
-		const bool better = best_id < 0 || key > best || (key == best && (mode == 1 ? i > best_id : i < best_id));
-		if (better) { best = key; best_id = i; }
+		if (occ_better(key, i, best, best_id, mode)) { best = key; best_id = i; }
 	}
 	s_key[tid] = best; s_id[tid] = best_id; s_cnt[tid] = cnt;
 	__syncthreads();
-	for (int o = 512; o > 0; o >>= 1)
+	for (int o = OCC_THREADS / 2; o > 0; o >>= 1)
 	{
 		if (tid < o)
 		{
-			const int j = s_id[tid + o];
-			if (j >= 0)
-			{
-				const int b = s_id[tid];
-				const double kj = s_key[tid + o], kb = s_key[tid];
-				if (b < 0 || kj > kb || (kj == kb && (mode == 1 ? j > b : j < b))) { s_key[tid] = kj; s_id[tid] = j; }
-			}
+			if (occ_better(s_key[tid + o], s_id[tid + o], s_key[tid], s_id[tid], mode)) { s_key[tid] = s_key[tid + o]; s_id[tid] = s_id[tid + o]; }
+			s_cnt[tid] += s_cnt[tid + o];
+		}
+		__syncthreads();
+	}
+	if (tid == 0) { part_key[blockIdx.x] = s_key[0]; part_id[blockIdx.x] = s_id[0]; part_cnt[blockIdx.x] = s_cnt[0]; }
+}
+// stage 2.  mode 0: largest (ties: smallest id) -- build_connected_freespace's robot label.
+// Frontier modes (only components with size > min_area): 1 largest (ties: largest id, the reversed argsort of astar.py:581),
+// 2 combined size / (mean distance + 20) with a strict ">" in label order (ties: smallest id), 3 closest mean distance
+// with a strict "<" (ties: smallest id).  out = {chosen id or -1, its size, number of qualifying components}.
+__global__ __launch_bounds__(OCC_SELECT_BLOCKS) void k_cc_select(const double* __restrict__ part_key, const int* __restrict__ part_id,
+                                                                const int* __restrict__ part_cnt, const uint32_t* __restrict__ size, int mode,
+                                                                int* __restrict__ out)
+{
+	__shared__ double s_key[OCC_SELECT_BLOCKS];
+	__shared__ int s_id[OCC_SELECT_BLOCKS];
+	__shared__ int s_cnt[OCC_SELECT_BLOCKS];
+	const int tid = threadIdx.x;
+	s_key[tid] = part_key[tid]; s_id[tid] = part_id[tid]; s_cnt[tid] = part_cnt[tid];
+	__syncthreads();
+	for (int o = OCC_SELECT_BLOCKS / 2; o > 0; o >>= 1)
+	{
+		if (tid < o)
+		{
+			if (occ_better(s_key[tid + o], s_id[tid + o], s_key[tid], s_id[tid], mode)) { s_key[tid] = s_key[tid + o]; s_id[tid] = s_id[tid + o]; }
 			s_cnt[tid] += s_cnt[tid + o];
 		}
 		__syncthreads();
@@ -401,7 +467,7 @@ __global__ __launch_bounds__(OCC_THREADS) void k_occ_cells_of(OccGeom g, const f
 // =========================================================================================================
 static inline size_t occ_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct OccLayout { size_t cnt, canvas, lab8, tmp_a, tmp_b, cc, size, dist, rows, sel, scalars, total; };
+struct OccLayout { size_t cnt, canvas, lab8, tmp_a, tmp_b, cc, size, dist, rows, sel, part, scalars, total; };
 
 static OccLayout occ_layout(const fr_occ_cfg* c)
 {
@@ -418,6 +484,7 @@ static OccLayout occ_layout(const fr_occ_cfg* c)
 	L.dist = o; o = occ_align(o + n * 8);
 	L.rows = o; o = occ_align(o + (size_t)c->grid_h * 4);
 	L.sel = o; o = occ_align(o + 64);
+	L.part = o; o = occ_align(o + (size_t)OCC_SELECT_BLOCKS * 16);      // stage-1 results of the component selection: key f64, id i32, count i32
 	L.scalars = o; o = occ_align(o + 64);
 	L.total = o;
 	return L;
@@ -523,8 +590,13 @@ extern "C" int fr_occ_freespace(const fr_occ_cfg* cfg, const float* occ_map, con
 	hipLaunchKernelGGL((k_occ_morph<false>), occ_grid(n), dim3(OCC_THREADS), 0, s, g, (const uint8_t*)tb, ta, 3);
 	// largest component (astar.py:438-445)
 	occ_components(g, L, ws, ta, false, 0, 0, s);
-	hipLaunchKernelGGL(k_cc_select, dim3(1), dim3(1024), 0, s, (int)n, (const int*)(ws + L.cc), (const uint32_t*)(ws + L.size),
-	                   (const double*)nullptr, 0, 0u, sel);
+	{
+		double* pk = (double*)(ws + L.part); int* pi = (int*)(pk + OCC_SELECT_BLOCKS); int* pc = pi + OCC_SELECT_BLOCKS;
+		hipLaunchKernelGGL(k_cc_select_partial, dim3(OCC_SELECT_BLOCKS), dim3(OCC_THREADS), 0, s, (int)n, (const int*)(ws + L.cc),
+		                   (const uint32_t*)(ws + L.size), (const double*)nullptr, 0, 0u, pk, pi, pc);
+		hipLaunchKernelGGL(k_cc_select, dim3(1), dim3(OCC_SELECT_BLOCKS), 0, s, (const double*)pk, (const int*)pi, (const int*)pc,
+		                   (const uint32_t*)(ws + L.size), 0, sel);
+	}
 	hipLaunchKernelGGL(k_cc_mask, occ_grid(n), dim3(OCC_THREADS), 0, s, (int)n, (const int*)(ws + L.cc), (const int*)sel, free_space);
 	return fr_check_launch("fr_occ_freespace");
 }
@@ -557,8 +629,13 @@ extern "C" int fr_occ_frontiers(const fr_occ_cfg* cfg, const float* occ_map, con
 	hipLaunchKernelGGL(k_occ_frontier, occ_grid(n), dim3(OCC_THREADS), 0, s, (int)n, (const uint8_t*)ta, free_space, (const uint8_t*)lab8, frontier, counts);
 	hipLaunchKernelGGL((k_occ_morph<false>), occ_grid(n), dim3(OCC_THREADS), 0, s, g, (const uint8_t*)frontier, tb, 3);
 	occ_components(g, L, ws, tb, true, cam_row, cam_col, s);
-	hipLaunchKernelGGL(k_cc_select, dim3(1), dim3(1024), 0, s, (int)n, (const int*)(ws + L.cc), (const uint32_t*)(ws + L.size),
-	                   (const double*)(ws + L.dist), method + 1, (uint32_t)min_area, sel);
+	{
+		double* pk = (double*)(ws + L.part); int* pi = (int*)(pk + OCC_SELECT_BLOCKS); int* pc = pi + OCC_SELECT_BLOCKS;
+		hipLaunchKernelGGL(k_cc_select_partial, dim3(OCC_SELECT_BLOCKS), dim3(OCC_THREADS), 0, s, (int)n, (const int*)(ws + L.cc),
+		                   (const uint32_t*)(ws + L.size), (const double*)(ws + L.dist), method + 1, (uint32_t)min_area, pk, pi, pc);
+		hipLaunchKernelGGL(k_cc_select, dim3(1), dim3(OCC_SELECT_BLOCKS), 0, s, (const double*)pk, (const int*)pi, (const int*)pc,
+		                   (const uint32_t*)(ws + L.size), method + 1, sel);
+	}
 	hipLaunchKernelGGL(k_cc_mask, occ_grid(n), dim3(OCC_THREADS), 0, s, (int)n, (const int*)(ws + L.cc), (const int*)sel, target);
 	hipLaunchKernelGGL(k_row_count, dim3(g.gh), dim3(OCC_THREADS), 0, s, g, (const uint8_t*)target, rows);
 	hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, s, g.gh, rows, counts + 2);
