@@ -3022,6 +3022,7 @@ __device__ __forceinline__ float fr_dec_f(uint32_t e)
 
 __global__ __launch_bounds__(FR_THREADS) void k_knn_minmax(int P, const float* __restrict__ pts, uint32_t* __restrict__ mm)
 {
+	__shared__ float s_lo[3][4], s_hi[3][4];
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (int i = blockIdx.x * FR_THREADS + threadIdx.x; i < P; i += gridDim.x * FR_THREADS)
 #pragma unroll
@@ -3031,7 +3032,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_knn_minmax(int P, const float* _
 	{
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
-		if ((threadIdx.x & 63) == 0) { atomicMin(&mm[a], fr_enc_f(lo[a])); atomicMax(&mm[3 + a], fr_enc_f(hi[a])); }
+		if ((threadIdx.x & 63) == 0) { s_lo[a][threadIdx.x >> 6] = lo[a]; s_hi[a][threadIdx.x >> 6] = hi[a]; }
+	}
+	__syncthreads();
+	// one pair of atomics per workgroup and axis: they all land on the same six words
+	if (threadIdx.x < 3)
+	{
+		const int a = threadIdx.x;
+		const float l = fminf(fminf(s_lo[a][0], s_lo[a][1]), fminf(s_lo[a][2], s_lo[a][3]));
+		const float h = fmaxf(fmaxf(s_hi[a][0], s_hi[a][1]), fmaxf(s_hi[a][2], s_hi[a][3]));
+		atomicMin(&mm[a], fr_enc_f(l)); atomicMax(&mm[3 + a], fr_enc_f(h));
 	}
 }
 
@@ -3274,7 +3284,7 @@ extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* wo
 	(void)hipMemsetAsync(mm, 0xFF, 12, s);
 	(void)hipMemsetAsync(mm + 3, 0x00, 12, s);
 	const int nblk = (P + FR_THREADS - 1) / FR_THREADS;
-	hipLaunchKernelGGL(k_knn_minmax, dim3(nblk < 1024 ? nblk : 1024), dim3(FR_THREADS), 0, s, P, points, mm);
+	hipLaunchKernelGGL(k_knn_minmax, dim3(nblk < 256 ? nblk : 256), dim3(FR_THREADS), 0, s, P, points, mm);
 	if ((rc = fr_check_launch("k_knn_minmax"))) return rc;
 	hipLaunchKernelGGL(k_knn_morton, dim3(nblk), dim3(FR_THREADS), 0, s, P, points, mm, keys);
 	if ((rc = fr_check_launch("k_knn_morton"))) return rc;
