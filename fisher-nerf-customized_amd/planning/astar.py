@@ -69,7 +69,7 @@ class OccupancyOps:
         pose = pose.detach().cpu().numpy() if isinstance(pose, torch.Tensor) else np.asarray(pose)
         self.grid_dim = np.array([768, 768])
         self.intrinsics = intrinsic
-        self.cam_height = pose[1, 3]
+        self.cam_height = float(pose[1, 3])
         if scene_bounds is not None:
             self.scene_bounds = scene_bounds
             scene_lower, scene_upper = scene_bounds
@@ -195,12 +195,12 @@ class OccupancyOps:
         theta = torch.rand((K,), device=dev) * 2 * torch.pi
         random_radius = self.min_range + torch.rand((K,), device=dev) * (radius - self.min_range)
         center_point = center_point.to(dev)
-        center_point_height = torch.ones((center_point.shape[0],), device=dev) * self.cam_height
+        center_point_height = torch.ones((center_point.shape[0],), device=dev) * float(self.cam_height)
         center_point = torch.stack([center_point[:, 0], center_point_height, center_point[:, 1]], dim=1)
         center_point = center_point[torch.randint(0, center_point.shape[0], (K,), device=dev)]
         cam_pos = torch.zeros((K, 3), device=dev)
         cam_pos[:, 0] = center_point[:, 0] + random_radius * torch.sin(theta)
-        cam_pos[:, 1] = self.cam_height
+        cam_pos[:, 1] = float(self.cam_height)
         cam_pos[:, 2] = center_point[:, 2] + random_radius * torch.cos(theta)
         cam_rot = torch.zeros((K, 4), device=dev)
         theta = theta + torch.pi
