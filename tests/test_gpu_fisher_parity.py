@@ -389,3 +389,38 @@ def test_odd_shapes_against_oracle(gpu, oracle, P, V, W, H, columns, seed):
     for v in range(min(V, 3)):
         _, _, fwd, _ = oracle.compute_hessian(ocam, w2c[v].numpy(), *args, columns=columns, return_all=True)
         assert int(r["num_rendered"][v]) == fwd["num_rendered"]
+
+
+def test_object_variant_with_appended_random_gaussians(config1, gpu, oracle):
+    """GaussianObjectSLAM.compute_Hessian / pose_eval with `random_gaussian_params` (gaussian_object.py:1971-1992): the extra
+    Gaussians are appended with colour 0.5, their rotations un-normalised and their opacity taken as given."""
+    import models.gaussian_slam as mgs
+    c = config1
+    slam = mgs.GaussianObjectSLAM(params=c["params"], intrinsics=c["K"], width=c["W"], height=c["H"], device=gpu)
+    g = torch.Generator().manual_seed(17)
+    Nr = 1500
+    rg = dict(means3D=(torch.rand((Nr, 3), generator=g) - 0.5) * torch.tensor([8.0, 2.0, 8.0]),
+              rotations=torch.randn((Nr, 4), generator=g) * 1.3,                 # deliberately not unit length
+              opacity=torch.rand((Nr, 1), generator=g) * 0.8 + 0.1,
+              scales=torch.rand((Nr, 3), generator=g) * 0.05 + 0.01)
+    w2c = torch.linalg.inv(c["c2w"][3])
+    cur_H, pose_H, vis = slam.compute_Hessian(w2c.to(gpu), return_points=True, random_gaussian_params=rg, return_pose=True)
+    P = c["P"]
+    assert cur_H.shape == (P + Nr, 11) and pose_H.shape == (6, 6)
+    a = {k: v.numpy() for k, v in c["act"].items()}
+    means = np.concatenate([a["means3D"], rg["means3D"].numpy()]).astype(np.float32)
+    cols = np.concatenate([a["rgb_colors"], np.full((Nr, 3), 0.5, np.float32)]).astype(np.float32)
+    rots = np.concatenate([a["rotations"], rg["rotations"].numpy()]).astype(np.float32)
+    ops = np.concatenate([a["opacities"].reshape(-1, 1), rg["opacity"].numpy()]).astype(np.float32)
+    scs = np.concatenate([a["scales"], rg["scales"].numpy()]).astype(np.float32)
+    H_o, vis_o, _, _ = oracle.compute_hessian(c["ocam"], w2c.numpy(), means, cols, rots, ops, scs, columns=11, return_all=True)
+    assert vis == vis_o
+    # un-normalised quaternions make the rotation rows a difference of large terms: the floor is 1e-5 of the largest entry here
+    assert_close(cur_H.cpu().numpy(), H_o, 1e-4, "cur_H with random Gaussians", atol_frac=1e-5)
+    assert float(cur_H[P:].abs().sum()) > 0                                          # the appended ones do receive information
+    for kf in c["kf_w2c"][:2]:
+        slam.add_keyframe(kf)
+    scores, c2ws = slam.pose_eval([p.to(gpu) for p in c["c2w"][:3]], random_gaussian_params=rg)
+    H_train_o = oracle.compute_h_train(c["ocam"], c["kf_w2c"][:2].numpy(), means, cols, rots, ops, scs, columns=11)
+    want, _ = oracle.pose_eval(c["ocam"], c["w2c"][:3].numpy(), H_train_o, means, cols, rots, ops, scs, columns=11)
+    assert rel_err(scores.numpy(), want) < 1e-4 and c2ws.shape == (3, 4, 4)
