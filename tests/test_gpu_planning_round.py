@@ -54,3 +54,65 @@ def test_planning_round_on_the_synthetic_room(gpu):
     kf = torch.stack([kf["est_w2c"] for kf in slam.keyframe_list])
     s2, _ = D.pose_eval_sharded(sc, kf, torch.linalg.inv(c2ws))
     assert torch.allclose(s2.cpu(), scores, rtol=1e-5, atol=0)
+
+
+def test_install_on_reference_shaped_classes(gpu):
+    """INTEGRATION.md 4 / 4b, functionally: classes that only carry the attributes the reference's constructors set get the
+    accelerated methods through `install` and produce the same numbers as the standalone carriers."""
+    from fisher_rast import synthetic
+    from oracle.occupancy_frontier import room_depth
+    from models.SLAM.gaussian import FisherOps
+    from models.SLAM.utils.recon_helpers import setup_camera
+    from planning.astar import OccupancyOps
+    import planning
+    import models.gaussian_slam as mgs
+    W = H = 96
+    K = synthetic.intrinsics(W, H)
+    params = {k: v.to(gpu) for k, v in synthetic.room_shell(8000, 9).items()}
+    kfs = [w.to(gpu) for w in synthetic.invert_rigid(synthetic.candidate_poses(3, 109))]
+    poses = [p.to(gpu) for p in synthetic.candidate_poses(5, 9)]
+
+    class RefSLAM:                                   # what models/SLAM/gaussian.py:GaussianSLAM holds when pose_eval is called
+        def __init__(self):
+            self.params = params
+            self.cam = setup_camera(W, H, K, np.eye(4), device=gpu)
+            self.keyframe_list = [dict(est_w2c=w, id=i) for i, w in enumerate(kfs)]
+    FisherOps.install(RefSLAM)
+    got, c2ws = RefSLAM().pose_eval(poses)
+    ours = mgs.GaussianSLAM(params=params, intrinsics=K, width=W, height=H, device=gpu)
+    for w in kfs:
+        ours.add_keyframe(w)
+    want, _ = ours.pose_eval(poses)
+    assert torch.equal(got, want) and c2ws.shape == (5, 4, 4)
+
+    class RefPlanner:                                # attributes of planning/astar.py:AstarPlanner.__init__ / init (23-103)
+        def __init__(self):
+            self.device = gpu
+            self.cell_size, self.height_upper, self.height_lower = 0.05, 0.6, -0.6
+            self.K, self.radius, self.min_range = 16, 1.0, 0.2
+            self.frontier_select_method, self.pcd_far_distance = "largest", 10.0
+            self.grid_dim = np.array([768, 768])
+            self.intrinsics = torch.from_numpy(np.asarray(K, dtype=np.float32))
+            pose = torch.eye(4)
+            self.cam_height = pose[1, 3]                                     # a 0-dim tensor in the reference
+            self.occ_map = torch.zeros((3, 768, 768), device=gpu)
+            self.occ_map[0] = 1.
+            self.cam_pos = np.array([384, 384])
+            self.occ_map[2, 383:386, 383:386] = 2.
+            self.map_center = torch.from_numpy(pose[[0, 2], 3].numpy()).to(gpu)
+            self.frame_idx = 0
+    OccupancyOps.install(RefPlanner)
+    ref_pl = RefPlanner()
+    our_pl = planning.AstarPlanner(device=gpu, cell_size=0.05, frontier_select_method="largest", sample_view_num=16)
+    our_pl.init(torch.eye(4), torch.from_numpy(np.asarray(K, dtype=np.float32)))
+    for t, p in enumerate(synthetic.candidate_poses(6, 309).numpy().astype(np.float32)):
+        d = room_depth(p, W, H, K)
+        ref_pl.update_occ_map(d, torch.from_numpy(p).to(gpu), t)
+        our_pl.update_occ_map(d, torch.from_numpy(p).to(gpu), t)
+    assert torch.equal(ref_pl.occ_map, our_pl.occ_map)
+    f1, s1 = ref_pl.build_frontiers(params["means3D"])
+    f2, s2 = our_pl.build_frontiers(params["means3D"])
+    assert np.array_equal(s1, s2) and ((f1 is None) == (f2 is None)) and (f1 is None or np.array_equal(f1, f2))
+    torch.manual_seed(1)
+    cand = ref_pl.generate_candidate(torch.zeros((3, 2), device=gpu))
+    assert cand.shape == (16, 4, 4)
