@@ -1798,6 +1798,345 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 	if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Third-generation scorer (score-only mode: H_inv given, no out_H, constant upstream gradient): ONE front-to-back pass.
+//
+// The reference's backward (backward.cu:960-1038) walks a pixel's contributors back to front because dL_dalpha_i needs
+// the colour accumulated BEHIND splat i.  With the same upstream gradient g on every channel, write cg_i = sum_ch c_i[ch],
+// b_i = 1/(1 - alpha_i), Cg_<=i = sum_{j<=i} cg_j alpha_j T_j (front-to-back prefix of the composited colour) and
+// X = Cg_final + T_final * sum_ch bg[ch]  (known only when the pixel is finished).  Then
+//     dL_dalpha_i / g = T_i cg_i - (X - Cg_<=i) b_i = p_i - X b_i ,      p_i = T_i cg_i + Cg_<=i b_i ,
+// and the pixel's share of the score, sum_i S_i (p_i - X b_i)^2 with S_i = (opacity G_i)^2 (u'^T Q_i u' + k3_i) the
+// geometry factor of the pair (see k_fisher_records), expands to  A - 2 X B + X^2 D  with three running sums
+//     A = sum S_i p_i^2 ,   B = sum S_i p_i b_i ,   D = sum S_i b_i^2
+// that a FORWARD walk can keep.  The transmittance pass, the per-strip contributor lists and the second gather of every
+// record disappear.  To keep the expansion from cancelling on low-contrast pixels the sums are taken about a per-pixel
+// centre Xt (the colour of the pixel's first contributor): p'_i = p_i - Xt b_i, result A' - 2 (X - Xt) B' + (X - Xt)^2 D.
+// Contributor rules are the forward's (forward.cu:347-366): power > 0 or alpha < 1/255 skips, test_T < 1e-4 ends the pixel.
+//
+// Everything that depends on (view, Gaussian) only -- the Jacobian chain of backward.cu:335-475 pushed through unit vectors
+// and folded with H_inv into the 5x5 form Q -- is computed ONCE per visible (view, Gaussian) by k_fisher_records instead of
+// once per (strip, list entry) inside the tile kernel, and stored as 96 bytes:
+//     recA {x, y, ext, log2(opacity)}   recB {-conic.x/2, -conic.y, -conic.z/2, cg}    (in place of the FrSplat record)
+//     recQ {Q'[15], k3}                                                                 (64 B, [V][P])
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const FrFisherArgs& f, const float* __restrict__ packed,
+                                                     float4* __restrict__ recq, int v, uint32_t id,
+                                                     const float* vm, const float* pm, const float* wm, bool has_w2c)
+{
+	constexpr int PS = FrPackSize<C>::value;
+	constexpr bool SR = C >= 11;
+	float4* sp = (float4*)(p.splat + (size_t)v * p.P + id);
+	const float4 a0 = sp[0], a1 = sp[1];                 // {x, y, cx, cy} {cz, o, depth, ext}
+	float gsv[PS];
+	const float4* pk = (const float4*)(packed + (size_t)id * PS);
+#pragma unroll
+	for (int q = 0; q < PS / 4; q++) { const float4 t4 = pk[q]; gsv[4 * q] = t4.x; gsv[4 * q + 1] = t4.y; gsv[4 * q + 2] = t4.z; gsv[4 * q + 3] = t4.w; }
+	const fr_f3 pw = { gsv[0], gsv[1], gsv[2] };
+	const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+	float A[3][5];
+	float B[6][3];
+	fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr);
+	// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
+	// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
+	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+	float Ap[3][5];
+#pragma unroll
+	for (int r = 0; r < 3; r++)
+	{
+		Ap[r][0] = A[r][0] * ddelx_dx; Ap[r][1] = A[r][1] * ddely_dy;
+#pragma unroll
+		for (int c = 2; c < 5; c++) Ap[r][c] = -0.5f * A[r][c];
+	}
+	float Cp[SR ? 7 : 1][3];
+	int go = 12;
+	if constexpr (SR)
+	{
+		const fr_f3 sc = { gsv[12], gsv[13], gsv[14] };
+		const fr_f4 qr = { gsv[15], gsv[16], gsv[17], gsv[18] };
+		float Cm[7][3];
+		fr_scale_rot_jacobian(sc, p.mod, qr, B, Cm);
+#pragma unroll
+		for (int r = 0; r < 7; r++)
+#pragma unroll
+			for (int c = 0; c < 3; c++) Cp[r][c] = -0.5f * Cm[r][c];
+		go = 19;
+	}
+	float hv[C];
+	if (f.hinv_stride != 0)
+	{
+		const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
+#pragma unroll
+		for (int c = 0; c < C; c++) hv[c] = hp[c];
+	}
+	else
+	{
+#pragma unroll
+		for (int c = 0; c < C; c++) hv[c] = gsv[go + c];
+	}
+	// upper triangle of Q = sum_c H_inv[c] M_c^T M_c, row-major, off-diagonal entries doubled: u'^T Q u' = sum_{i <= j} Q'[ij] u_i u_j
+	float qf[16];
+	int q = 0;
+#pragma unroll
+	for (int i = 0; i < 5; i++)
+#pragma unroll
+		for (int j = i; j < 5; j++)
+		{
+			float acc = hv[0] * Ap[0][i] * Ap[0][j] + hv[1] * Ap[1][i] * Ap[1][j] + hv[2] * Ap[2][i] * Ap[2][j];
+			if constexpr (SR)
+			{
+				if (i >= 2)
+				{
+#pragma unroll
+					for (int r = 0; r < 7; r++) acc += hv[4 + r] * Cp[r][i - 2] * Cp[r][j - 2];
+				}
+			}
+			qf[q++] = (i == j) ? acc : 2.0f * acc;
+		}
+	const float inv_o = __builtin_amdgcn_rcpf(a1.y);
+	qf[15] = inv_o * inv_o * hv[3];                      // dL_dopacity = G dL_dalpha = w / opacity, weighted by H_inv[3]
+	sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
+	sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
+	float4* dq = recq + ((size_t)v * p.P + id) * 4;
+#pragma unroll
+	for (int k = 0; k < 4; k++) dq[k] = make_float4(qf[4 * k], qf[4 * k + 1], qf[4 * k + 2], qf[4 * k + 3]);
+}
+
+// one workgroup per (preprocess workgroup, view): walks that workgroup's compact visible list, all lanes busy
+template <int C, bool LIST>
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
+                                                               float4* __restrict__ recq)
+{
+	if (p.status[1]) return;
+	const int tid = threadIdx.x;
+	const int v = blockIdx.y;
+	const uint32_t nblk = gridDim.x;
+	float vm[16], pm[16], wm[12];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const bool has_w2c = p.w2c != nullptr;
+#pragma unroll
+	for (int k = 0; k < 12; k++) wm[k] = has_w2c ? p.w2c[16 * (size_t)v + k] : 0.f;
+	if constexpr (LIST)
+	{
+		const uint32_t n = p.vis_n[(size_t)v * nblk + blockIdx.x];
+		const FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * (size_t)(FR_THREADS * p.G);
+		for (uint32_t e = tid; e < n; e += FR_THREADS)
+			fr_fisher_record_one<C>(p, f, packed, recq, v, list[e].idx, vm, pm, wm, has_w2c);
+	}
+	else
+	{
+		// single-view front end (images beyond FR_MAX_LDS_TILES tiles): visibility from radii
+		for (int g = 0; g < p.G; g++)
+		{
+			const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
+			if (i < p.P && p.radii[(size_t)v * p.P + i] > 0)
+				fr_fisher_record_one<C>(p, f, packed, recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
+		}
+	}
+}
+
+#define FR_QCAP 128                  // per-wave candidate queue (ring of Gaussian indices): at most 63 left over + 64 new
+// One workgroup per (tile, view); the four waves own the four 16x4 strips and never synchronise until the final sum.
+//  stream   a wave reads the tile's sorted keys 64 at a time (one per lane), gathers recA and keeps the splats whose
+//           conservative alpha footprint meets its strip (one ballot); survivors are appended, in order, to a ring in LDS;
+//  chunk    64 queued candidates, one per lane: the lane gathers recB + recQ and parks the 96-byte record in LDS; it
+//           rasterises its footprint ellipse row by row into a 64-bit mask over the strip's pixels, and a 64x64 bit
+//           transpose across the wave hands every pixel-lane the mask of candidates that may touch it;
+//  walk     every pixel-lane walks its own set bits front to back: six ds_read_b128 of the candidate's record, the pair
+//           test, the transmittance / colour prefix recurrences and the three sums.  A finished pixel clears its masks;
+//           a wave whose 64 pixels are finished leaves.
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5)))
+void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
+{
+	__shared__ uint32_t s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][64][6];
+	__shared__ float s_red[4];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* rec = (const float4*)(p.splat + vP);
+	const float4* rq = recq + vP * 4;
+	uint32_t* wq = s_q[wave];
+	float4 (*ent)[6] = s_ent[wave];
+
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+	float T = 1.0f, Cg = 0.f, Xt = 0.f, sA = 0.f, sB = 0.f, sD = 0.f;
+	bool done = !inside;
+	uint32_t qh = 0, qn = 0;                       // ring head / fill, wave-uniform
+#ifdef FR_LOOPSTATS
+	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0, dbg_cs = 0;
+#endif
+
+	// software pipeline of the key stream: id1 / r1 = indices and recA of the chunk at `base`, id2 = indices of the next one
+	uint32_t id1 = 0, id2 = 0;
+	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[2 * (size_t)id1]; }
+	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
+	uint32_t base = 0;
+	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	while (!all_done)
+	{
+		// ---- stream: fill the queue up to one chunk
+		while (qn < 64u && base < n)
+		{
+			const uint32_t idc = id1; const float4 rc = r1;
+			id1 = id2;
+			if (base + 64 + lane < n) r1 = rec[2 * (size_t)id2];
+			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
+			const uint32_t eb = __float_as_uint(rc.z);
+			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			const bool ov = (base + lane < n) && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi)
+			                && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc;
+			qn += (uint32_t)__popcll(om);
+			base += 64;
+		}
+		if (qn == 0) break;
+		// ---- chunk: up to 64 candidates, one per lane
+		const uint32_t m = qn < 64u ? qn : 64u;
+#ifdef FR_LOOPSTATS
+		dbg_chunks++; dbg_cand += (int)m;
+#endif
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		unsigned long long emask = 0ull;
+		if ((uint32_t)lane < m)
+		{
+			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
+			const float4 a = rec[2 * (size_t)id], b4 = rec[2 * (size_t)id + 1];
+			const float4 q0 = rq[4 * (size_t)id], q1 = rq[4 * (size_t)id + 1], q2 = rq[4 * (size_t)id + 2], q3 = rq[4 * (size_t)id + 3];
+			ent[lane][0] = a; ent[lane][1] = b4; ent[lane][2] = q0; ent[lane][3] = q1; ent[lane][4] = q2; ent[lane][5] = q3;
+			const float ax = a.x, ay = a.y;
+			const uint32_t eb = __float_as_uint(a.z);
+			const float ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			const float ahy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			const float acx = -2.0f * b4.x, acy = -b4.y, acz = -2.0f * b4.z;
+			// conservative lower bound on `power` below which alpha < 1/255: -ln(255 opacity) - 0.01 (fr_power_threshold)
+			const float athr = -(5.541263545158426f + 0.6931471805599453f * a.w) - 0.01f;
+			// Row by row: power(dx, dy) >= thr  <=>  cx dx^2 + 2 cy dy dx + (cz dy^2 + 2 thr) <= 0, an interval in dx
+			// (d = mean - pixel).  Widened by 1 % + 0.01 px, so it stays a superset of the exact test done in the walk.
+			const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
+			const float racx = __builtin_amdgcn_rcpf(acx);
+#pragma unroll
+			for (unsigned r = 0; r < 4; r++)
+			{
+				const float dy = ay - (strip_lo + (float)r);
+				float lo = ax - ahx, hi2 = ax + ahx;                  // box fallback (unknown / degenerate conic)
+				bool any_px = fabsf(dy) <= ahy;
+				if (quad_ok)
+				{
+					const float hb = acy * dy;                         // b / 2
+					const float cq = acz * dy * dy + 2.0f * athr;
+					const float disc = hb * hb - acx * cq;             // (b^2 - 4ac) / 4
+					any_px = any_px && (disc >= 0.f);
+					const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
+					const float dlo = (-hb - sq) * racx, dhi = (-hb + sq) * racx;   // dx in [dlo, dhi]
+					lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;               // pixel x = mean.x - dx
+				}
+				const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, 15.f);
+				if (any_px && c0f <= c1f)
+				{
+					const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f;
+					const unsigned long long cols = (unsigned long long)(((2u << c1) - 1u) & ~((1u << c0) - 1u));
+					emask |= cols << (16 * r);
+				}
+			}
+		}
+		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (done) mask = 0ull;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- walk: every pixel-lane walks its own candidates front to back
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 a = ent[j][0], b4 = ent[j][1], q0 = ent[j][2], q1 = ent[j][3], q2 = ent[j][4], q3 = ent[j][5];
+#ifdef FR_LOOPSTATS
+			dbg_steps++; dbg_cs++;
+#endif
+			const float dx = a.x - pfx, dy = a.y - pfy;
+			float power;
+			const float e = fr_scorer_exponent(b4.x, b4.y, b4.z, dx, dy, a.w, power);
+			// forward.cu:347-357 (power > 0 -> skip, alpha < 1/255 -> skip); NaN falls through as it does there
+			if ((power > 0.0f) || (e < FR_E255)) continue;
+			{
+#pragma clang fp contract(fast)
+				const float a_un = __builtin_amdgcn_exp2f(e);                          // opacity * G
+				const float alpha = fminf(0.99f, a_un);
+				const float om1 = 1.f - alpha;
+				const float test_T = T * om1;
+				if (test_T < 0.0001f) { mask = 0ull; done = true; continue; }          // forward.cu:358-363
+#ifdef FR_LOOPSTATS
+				dbg_hits++;
+#endif
+				const float bi = __builtin_amdgcn_rcpf(om1);
+				const float cg = b4.w;
+				Xt = (T == 1.0f) ? cg : Xt;                                            // centre: the first contributor's colour
+				Cg = Cg + cg * (alpha * T);
+				const float pc = (Cg - Xt) * bi + T * cg;                              // p_i - Xt b_i
+				T = test_T;
+				float u[5];
+				u[0] = b4.x * dx + (b4.x * dx + b4.y * dy);                            // -(cx dx + cy dy)
+				u[1] = 2.0f * (b4.z * dy) + b4.y * dx;                                 // -(cz dy + cy dx)
+				u[2] = dx * dx; u[3] = dx * dy; u[4] = dy * dy;
+				const float qv[15] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z };
+				float add = q3.w;
+				int q = 0;
+#pragma unroll
+				for (int i = 0; i < 5; i++)
+				{
+					float ti = 0.f;
+#pragma unroll
+					for (int jj = i; jj < 5; jj++) ti += qv[q++] * u[jj];
+					add += u[i] * ti;
+				}
+				const float S = (a_un * a_un) * add;
+				const float Sp = S * pc, Sb = S * bi;
+				sA += Sp * pc; sB += Sp * bi; sD += Sb * bi;
+			}
+		}
+		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+#ifdef FR_LOOPSTATS
+		dbg_wsteps += wave_max_i(dbg_cs); dbg_cs = 0;
+#endif
+	}
+	// X = Cg_final + T_final * sum(bg); pixel = A' - 2 (X - Xt) B' + (X - Xt)^2 D, times dL^2
+	const float X = Cg + T * (p.bg[0] + p.bg[1] + p.bg[2]);
+	const float dlt = X - Xt;
+	float score = inside ? (sA + dlt * (dlt * sD - 2.0f * sB)) : 0.f;
+	float ws = wave_sum(score);
+#ifdef FR_LOOPSTATS
+	if (f.debug_mode >= 2)
+	{
+		// 2: candidates, 3: chunks, 4: wave-level walk iterations, 5: contributing pairs, 6: lane-level walk steps
+		ws = f.debug_mode == 2 ? (float)dbg_cand : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_wsteps
+		   : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : wave_sum((float)dbg_steps);
+	}
+	else
+#endif
+	ws *= f.dL * f.dL;
+	if (lane == 0) s_red[wave] = ws;
+	__syncthreads();
+	if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
                                                               const int* __restrict__ status, float* __restrict__ out_scores)
 {
@@ -2865,7 +3204,7 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 }
 
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
@@ -2879,6 +3218,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.radii = o; o = fr_align(o + (size_t)V * nblk_v * (size_t)(FR_THREADS * fr_pick_G_views(P)) * sizeof(FrVisEntry));
 	L.vis_n = o; o = fr_align(o + (size_t)V * nblk_v * 4);
 	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
+	L.recq = o; o = fr_align(o + VP * 64);                // k_fisher_records: {Q'[15], k3} per (view, Gaussian), written where visible
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
 	L.blk_base = o; o = fr_align(o + (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4);
@@ -2902,7 +3242,7 @@ extern "C" size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int
 }
 
 template <int C>
-static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t* fallback, hipStream_t s)
+static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, float4* recq, bool list_mode, uint8_t* fallback, hipStream_t s)
 {
 	dim3 grid(p.T * p.V), block(FR_THREADS);
 	const bool hi = f.H_inv != nullptr, ho = f.out_H != nullptr;
@@ -2912,6 +3252,26 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t
 	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed);
 	// measurement hook: events around the dominant kernel only, on the stream it runs on
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (hi && !ho && !f.dL_img && f.debug_mode != 1 && f.debug_mode != 9)      // FR_DEBUG_MODE=9: second-generation kernel (A/B)
+	{
+		// score-only: per-(view, Gaussian) records once, then the single front-to-back pass (no capacity limit, no fallback)
+		const int per_block = FR_THREADS * p.G;
+		dim3 gridP((p.P + per_block - 1) / per_block, p.V);
+		if (list_mode) hipLaunchKernelGGL((k_fisher_records<C, true>), gridP, block, 0, s, p, f, (const float*)packed, recq);
+		else hipLaunchKernelGGL((k_fisher_records<C, false>), gridP, block, 0, s, p, f, (const float*)packed, recq);
+		if (g_prof_on)
+		{
+			(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+			(void)hipEventRecord(ev0, s);
+		}
+		hipLaunchKernelGGL(k_fisher_tile_v3, grid, block, 0, s, p, f, (const float4*)recq);
+		if (g_prof_on)
+		{
+			(void)hipEventRecord(ev1, s);
+			g_prof_events.push_back(std::make_pair(ev0, ev1));
+		}
+		return;
+	}
 	if (g_prof_on)
 	{
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
@@ -2987,8 +3347,9 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.tile_scores = (float*)(ws + L.tile_scores);
 	f.only_flagged = nullptr;
 	{ const char* dm = getenv("FR_DEBUG_MODE"); f.debug_mode = dm ? atoi(dm) : 0; }
-	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
-	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
+	const bool list_mode = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;     // the front end fr_bin_pipeline picked
+	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (float4*)(ws + L.recq), list_mode, (uint8_t*)(ws + L.fallback), s);
+	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (float4*)(ws + L.recq), list_mode, (uint8_t*)(ws + L.fallback), s);
 
 	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
 	if (fc->out_scores)
