@@ -1937,6 +1937,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrFis
 	}
 }
 
+#define FR_ENT_F4 7                   // float4 per parked candidate record: 6 used + 1 pad -- a 28-dword stride spreads sixteen consecutive
+                                     // candidates over all 64 LDS banks for ds_read_b128 (a 24-dword stride repeats after eight)
+typedef float fr_v4f __attribute__((ext_vector_type(4)));
 #define FR_QCAP 128                  // per-wave candidate queue (ring of Gaussian indices): at most 63 left over + 64 new
 // One workgroup per (tile, view); the four waves own the four 16x4 strips and never synchronise until the final sum.
 //  stream   a wave reads the tile's sorted keys 64 at a time (one per lane), gathers recA and keeps the splats whose
@@ -1951,7 +1954,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
 void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
 {
 	__shared__ uint32_t s_q[4][FR_QCAP];
-	__shared__ float4 s_ent[4][64][6];
+	__shared__ float4 s_ent[4][64][FR_ENT_F4];
 	__shared__ float s_red[4];
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -1969,7 +1972,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	const float4* rec = (const float4*)(p.splat + vP);
 	const float4* rq = recq + vP * 4;
 	uint32_t* wq = s_q[wave];
-	float4 (*ent)[6] = s_ent[wave];
+	float4 (*ent)[FR_ENT_F4] = s_ent[wave];
+	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];   // LDS byte address
 
 	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
 	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
@@ -2067,31 +2071,37 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		{
 			const int j = __ffsll((long long)mask) - 1;
 			mask &= mask - 1ull;
-			const float4 a = ent[j][0], b4 = ent[j][1], q0 = ent[j][2], q1 = ent[j][3], q2 = ent[j][4], q3 = ent[j][5];
+			// the candidate's 96-byte record: six ds_read_b128 (hipcc splits plain float4 loads into dword pairs here)
+			fr_v4f a, b4, q0, q1, q2, q3;
+			{
+				const uint32_t addr = ent_lds + (uint32_t)j * (FR_ENT_F4 * 16);
+				asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+				             "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
+				             "s_waitcnt lgkmcnt(0)"
+				             : "=&v"(a), "=&v"(b4), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
+			}
 #ifdef FR_LOOPSTATS
 			dbg_steps++; dbg_cs++;
 #endif
 			const float dx = a.x - pfx, dy = a.y - pfy;
 			float power;
 			const float e = fr_scorer_exponent(b4.x, b4.y, b4.z, dx, dy, a.w, power);
-			// forward.cu:347-357 (power > 0 -> skip, alpha < 1/255 -> skip); NaN falls through as it does there
-			if ((power > 0.0f) || (e < FR_E255)) continue;
 			{
 #pragma clang fp contract(fast)
+				// forward.cu:347-357 (power > 0 -> skip, alpha < 1/255 -> skip); NaN falls through as it does there
+				const bool ok = !(power > 0.0f) && !(e < FR_E255);
 				const float a_un = __builtin_amdgcn_exp2f(e);                          // opacity * G
 				const float alpha = fminf(0.99f, a_un);
 				const float om1 = 1.f - alpha;
 				const float test_T = T * om1;
-				if (test_T < 0.0001f) { mask = 0ull; done = true; continue; }          // forward.cu:358-363
+				const bool kill = ok && (test_T < 0.0001f);                            // forward.cu:358-363: the pixel is finished
+				const bool con = ok && !kill;
 #ifdef FR_LOOPSTATS
-				dbg_hits++;
+				dbg_hits += con ? 1 : 0;
 #endif
+				if (kill) { mask = 0ull; done = true; }
 				const float bi = __builtin_amdgcn_rcpf(om1);
 				const float cg = b4.w;
-				Xt = (T == 1.0f) ? cg : Xt;                                            // centre: the first contributor's colour
-				Cg = Cg + cg * (alpha * T);
-				const float pc = (Cg - Xt) * bi + T * cg;                              // p_i - Xt b_i
-				T = test_T;
 				float u[5];
 				u[0] = b4.x * dx + (b4.x * dx + b4.y * dy);                            // -(cx dx + cy dy)
 				u[1] = 2.0f * (b4.z * dy) + b4.y * dx;                                 // -(cz dy + cy dx)
@@ -2107,7 +2117,11 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 					for (int jj = i; jj < 5; jj++) ti += qv[q++] * u[jj];
 					add += u[i] * ti;
 				}
-				const float S = (a_un * a_un) * add;
+				const float S = con ? (a_un * a_un) * add : 0.f;
+				Xt = (con && T == 1.0f) ? cg : Xt;                                     // centre: the first contributor's colour
+				Cg = con ? Cg + cg * (alpha * T) : Cg;
+				const float pc = (Cg - Xt) * bi + T * cg;                              // p_i - Xt b_i
+				T = con ? test_T : T;
 				const float Sp = S * pc, Sb = S * bi;
 				sA += Sp * pc; sB += Sp * bi; sD += Sb * bi;
 			}
@@ -2125,9 +2139,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 #ifdef FR_LOOPSTATS
 	if (f.debug_mode >= 2)
 	{
-		// 2: candidates, 3: chunks, 4: wave-level walk iterations, 5: contributing pairs, 6: lane-level walk steps
+		// 2: candidates, 3: chunks, 4: wave-level walk iterations, 5: contributing pairs, 6: lane-level walk steps, 7: steps of the busiest lane
 		ws = f.debug_mode == 2 ? (float)dbg_cand : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_wsteps
-		   : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : wave_sum((float)dbg_steps);
+		   : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : f.debug_mode == 7 ? (float)wave_max_i(dbg_steps) : wave_sum((float)dbg_steps);
 	}
 	else
 #endif

@@ -1,0 +1,77 @@
+// valu_ceiling.hip -- calibration microbenchmark for the VALU roofline used by bench.py (MI355X / gfx950).
+// Measures how many wave64 VALU instructions one SIMD retires per nanosecond as a function of the number of resident
+// waves per SIMD and of the instruction-level parallelism inside a wave: the ceiling a VALU-bound kernel is priced against.
+//   build: hipcc -O3 --offload-arch=gfx950 -o tools/_build/valu_ceiling tools/valu_ceiling.hip
+//   run:   tools/_build/valu_ceiling            (prints one JSON line per configuration)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// ILP independent v_fma_f32 chains per lane; 64 FMAs per chain per outer iteration.
+template <int ILP, int KIND>
+__global__ __launch_bounds__(256) void k_stream(float* out, int iters, float c1, float c2)
+{
+	float a[ILP];
+#pragma unroll
+	for (int k = 0; k < ILP; k++) a[k] = (float)(threadIdx.x + k) * 1e-3f;
+	for (int i = 0; i < iters; i++)
+	{
+#pragma unroll
+		for (int r = 0; r < 64; r++)
+#pragma unroll
+			for (int k = 0; k < ILP; k++)
+			{
+				if (KIND == 0) a[k] = __builtin_fmaf(a[k], c1, c2);                 // v_fma_f32
+				else if (KIND == 1) a[k] = __builtin_amdgcn_exp2f(a[k]) * c1;      // v_exp_f32 + v_mul_f32
+				else a[k] = __int_as_float(__builtin_amdgcn_ds_bpermute((threadIdx.x & 63) << 2, __float_as_int(a[k]))) + c2;   // ds_bpermute_b32 + v_add_f32
+			}
+	}
+	float s = 0.f;
+#pragma unroll
+	for (int k = 0; k < ILP; k++) s += a[k];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ILP, int KIND>
+static void run(const char* name, int waves_per_simd, float* d_out, int insts_per_op)
+{
+	const int iters = 2000 / ILP > 0 ? 2000 / ILP : 1;
+	const int cus = 256;
+	dim3 grid(cus * waves_per_simd), block(256);       // a 256-thread workgroup = one wave on each of the 4 SIMDs of a CU
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	hipLaunchKernelGGL((k_stream<ILP, KIND>), grid, block, 0, 0, d_out, iters, 1.0001f, 1e-7f);
+	CHECK(hipDeviceSynchronize());
+	float best = 1e30f;
+	for (int rep = 0; rep < 5; rep++)
+	{
+		CHECK(hipEventRecord(e0, 0));
+		hipLaunchKernelGGL((k_stream<ILP, KIND>), grid, block, 0, 0, d_out, iters, 1.0001f, 1e-7f);
+		CHECK(hipEventRecord(e1, 0));
+		CHECK(hipEventSynchronize(e1));
+		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		if (ms < best) best = ms;
+	}
+	const double wave_insts = (double)grid.x * 4.0 * iters * 64.0 * ILP * insts_per_op;
+	const double per_simd_per_ns = wave_insts / 1024.0 / (best * 1e6);
+	printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"ilp\": %d, \"ms\": %.4f, \"wave_insts_per_ns_per_simd\": %.4f, "
+	       "\"cycles_per_inst_at_2.4GHz\": %.3f, \"chip_wave_insts_per_s\": %.4e}\n",
+	       name, waves_per_simd, ILP, best, per_simd_per_ns, 2.4 / per_simd_per_ns, per_simd_per_ns * 1e9 * 1024.0);
+}
+
+int main()
+{
+	float* d_out;
+	CHECK(hipMalloc(&d_out, (size_t)256 * 8 * 256 * sizeof(float)));
+	const int wl[] = { 1, 2, 4, 5, 8 };
+	for (int w : wl) run<1, 0>("v_fma_f32 dependent chain", w, d_out, 1);
+	for (int w : wl) run<4, 0>("v_fma_f32", w, d_out, 1);
+	for (int w : wl) run<8, 0>("v_fma_f32", w, d_out, 1);
+	for (int w : wl) run<4, 1>("v_exp_f32+v_mul_f32", w, d_out, 2);
+	for (int w : wl) run<4, 2>("ds_bpermute_b32+v_add_f32", w, d_out, 2);
+	CHECK(hipFree(d_out));
+	return 0;
+}
