@@ -444,6 +444,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 	}
 }
 
+// (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
+struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; };
+template <int C>
+__device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
+                                                     const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
+                                                     const float* vm, const float* pm, const float* wm, bool has_w2c);
+
 // ---------------------------------------------------------------------------------------------------------
 // Multi-view front end of the Fisher path (same camera, one rigid transform per candidate view).
 // k_preprocess is VALU-bound there: only ~1/4 of the (view, Gaussian) pairs are visible, so the ~400-instruction
@@ -454,7 +461,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 //            32-byte splat record, the per-(view, tile) LDS histogram, and one 16-byte entry per VISIBLE pair in
 //            this workgroup's compact list, which is all k_scatter_vis reads (no radii array, no idle lanes).
 // The arithmetic per pair is fr_preprocess_one's, so radii / rects / depths are bit-identical to k_preprocess.
-__global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p)
+//   phase C  (RC != 0: score-only mode) the workgroup walks the compact lists it has just written and turns every visible
+//            (view, Gaussian) into the scorer's 96-byte record (fr_fisher_record_one) while the splat records are still in L2.
+template <int RC>
+__global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrRecordArgs ra)
 {
 	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12]
 	const int VC = p.VC;
@@ -561,6 +571,22 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p)
 		const int v = v0 + tid;
 		p.vis_n[(size_t)v * nblk + blockIdx.x] = s_n[tid];
 		if (p.vis_count && s_n[tid]) atomicAdd(&p.vis_count[v], (int)s_n[tid]);
+	}
+	if constexpr (RC != 0)
+	{
+		// ---- phase C: the entries and splat records were written by this workgroup (same CU, same L1): visible after a barrier
+		__syncthreads();
+		for (int vv = 0; vv < nv; vv++)
+		{
+			const int v = v0 + vv;
+			const uint32_t n = s_n[vv];
+			const FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap;
+			float wm[12];
+#pragma unroll
+			for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * vv + k] : 0.f;
+			for (uint32_t e = tid; e < n; e += FR_THREADS)
+				fr_fisher_record_one<RC>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
+		}
 	}
 }
 
@@ -1821,8 +1847,8 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 //     recQ {Q'[15], k3}                                                                 (64 B, [V][P])
 // ---------------------------------------------------------------------------------------------------------
 template <int C>
-__device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const FrFisherArgs& f, const float* __restrict__ packed,
-                                                     float4* __restrict__ recq, int v, uint32_t id,
+__device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
+                                                     const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c)
 {
 	constexpr int PS = FrPackSize<C>::value;
@@ -1864,9 +1890,9 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const Fr
 		go = 19;
 	}
 	float hv[C];
-	if (f.hinv_stride != 0)
+	if (hinv_stride != 0)
 	{
-		const float* hp = f.H_inv + (size_t)v * f.hinv_stride + (size_t)id * C;
+		const float* hp = H_inv + (size_t)v * hinv_stride + (size_t)id * C;
 #pragma unroll
 		for (int c = 0; c < C; c++) hv[c] = hp[c];
 	}
@@ -1903,12 +1929,12 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const Fr
 	for (int k = 0; k < 4; k++) dq[k] = make_float4(qf[4 * k], qf[4 * k + 1], qf[4 * k + 2], qf[4 * k + 3]);
 }
 
-// one workgroup per (preprocess workgroup, view): walks that workgroup's compact visible list, all lanes busy
+// Stand-alone form of phase C of k_preprocess_views, for the single-view front end (images beyond FR_MAX_LDS_TILES tiles,
+// visibility from radii) -- or over the compact lists (LIST).  Needs the projection only, not the keys.
 template <int C, bool LIST>
-__global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
-                                                               float4* __restrict__ recq)
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRecordArgs ra)
 {
-	if (p.status[1]) return;
+	// (no overflow check: this kernel runs beside the scan that raises the flag)
 	const int tid = threadIdx.x;
 	const int v = blockIdx.y;
 	const uint32_t nblk = gridDim.x;
@@ -1923,16 +1949,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrFis
 		const uint32_t n = p.vis_n[(size_t)v * nblk + blockIdx.x];
 		const FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * (size_t)(FR_THREADS * p.G);
 		for (uint32_t e = tid; e < n; e += FR_THREADS)
-			fr_fisher_record_one<C>(p, f, packed, recq, v, list[e].idx, vm, pm, wm, has_w2c);
+			fr_fisher_record_one<C>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
 	}
 	else
 	{
-		// single-view front end (images beyond FR_MAX_LDS_TILES tiles): visibility from radii
 		for (int g = 0; g < p.G; g++)
 		{
 			const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
 			if (i < p.P && p.radii[(size_t)v * p.P + i] > 0)
-				fr_fisher_record_one<C>(p, f, packed, recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
+				fr_fisher_record_one<C>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
 		}
 	}
 }
@@ -2782,6 +2807,10 @@ static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t ma
 }
 
 extern "C" int fr_version(void) { return FR_VERSION; }
+#ifndef FR_SRC_HASH
+#define FR_SRC_HASH "unstamped"
+#endif
+extern "C" const char* fr_build_id(void) { return FR_SRC_HASH; }
 extern "C" const char* fr_last_error(void) { return g_err; }
 
 extern "C" int fr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_rendered, size_t out[3])
@@ -2873,13 +2902,15 @@ struct FrZeroer {
 	}
 };
 
-// One side stream per host thread for the fork/join inside fr_bin_pipeline (created on first use, lives with the thread).
+// Two side streams per host thread and device for the fork/joins inside fr_bin_pipeline (created on first use, or by
+// fr_init; they live with the thread): [0] the 1024-thread sort tier, [1] the scorer's per-(view, Gaussian) records.
 struct FrSideStream {
 	hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; int device = -1;
 };
-static FrSideStream& fr_side_stream()
+static FrSideStream& fr_side_stream(int which = 0)
 {
-	static thread_local FrSideStream ss;
+	static thread_local FrSideStream sides[2];
+	FrSideStream& ss = sides[which];
 	int dev = -1;
 	(void)hipGetDevice(&dev);
 	if (ss.device != dev)
@@ -2894,7 +2925,13 @@ static FrSideStream& fr_side_stream()
 	return ss;
 }
 
-static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
+// Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
+// k_preprocess_views; with the single-view front end, k_fisher_records beside scan / scatter / sort on the second side stream).
+struct FrScorerPlan { int columns; FrRecordArgs ra; };
+template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed);
+template <int C, bool LIST> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
+
+static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, const FrScorerPlan* plan = nullptr)
 {
 	int rc;
 	const int P = p.P;
@@ -2917,17 +2954,43 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 	const int per_block = FR_THREADS * p.G;
 	dim3 gridP((P + per_block - 1) / per_block, p.V);
 	const size_t hist_lds = p.T <= FR_MAX_LDS_TILES ? (size_t)p.T * 4 : 16;
+	if (plan)
+	{
+		const float* shared_hinv = plan->ra.hinv_stride ? nullptr : plan->ra.H_inv;
+		dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
+		if (plan->columns == 4) hipLaunchKernelGGL((k_pack_static<4>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed);
+		else hipLaunchKernelGGL((k_pack_static<11>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed);
+		if ((rc = fr_check_launch("k_pack_static"))) return rc;
+	}
+	FrSideStream* side2 = nullptr;
 	if (multi)
 	{
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC) * 4;
-		hipLaunchKernelGGL(k_preprocess_views, gridV, dim3(FR_THREADS), lds, s, p);
+		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr };
+		if (!plan) hipLaunchKernelGGL((k_preprocess_views<0>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		else hipLaunchKernelGGL((k_preprocess_views<11>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		if ((rc = fr_check_launch("k_preprocess_views"))) return rc;
 	}
 	else
 	{
 		hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
 		if ((rc = fr_check_launch("k_preprocess"))) return rc;
+		if (plan)
+		{
+			FrSideStream& s2 = fr_side_stream(1);
+			const bool forked2 = s2.ok && hipEventRecord(s2.fork, s) == hipSuccess && hipStreamWaitEvent(s2.stream, s2.fork, 0) == hipSuccess;
+			hipStream_t rs = forked2 ? s2.stream : s;
+			if (plan->columns == 4) hipLaunchKernelGGL((k_fisher_records<4, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
+			else hipLaunchKernelGGL((k_fisher_records<11, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
+			if ((rc = fr_check_launch("k_fisher_records"))) return rc;
+			if (forked2)
+			{
+				if (hipEventRecord(s2.join, s2.stream) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipEventRecord(join 2) failed");
+				side2 = &s2;
+			}
+		}
 	}
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
 	                   p.key_capacity, p.status, p.num_rendered, p.big_list);
@@ -2949,6 +3012,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s)
 	hipLaunchKernelGGL(k_sort_mid_tiles, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_mid_tiles"))) return rc;
 	if (forked && hipStreamWaitEvent(s, side.join, 0) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipStreamWaitEvent(join) failed");
+	if (side2 && hipStreamWaitEvent(s, side2->join, 0) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipStreamWaitEvent(join 2) failed");
 	return FR_OK;
 }
 
@@ -3217,6 +3281,13 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	return fr_check_launch("k_backward_finish");
 }
 
+// FR_DEBUG_MODE (timing ablations / loop statistics only), read once per process
+static int fr_debug_mode()
+{
+	static const int mode = [] { const char* dm = getenv("FR_DEBUG_MODE"); return dm ? atoi(dm) : 0; }();
+	return mode;
+}
+
 struct FrFisherLayout {
 	size_t radii, vis_n, splat, recq, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };
@@ -3249,14 +3320,46 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	return L;
 }
 
+extern "C" int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns, size_t o[8])
+{
+	if (P < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0 || (columns != 4 && columns != 11) || !o)
+		return fr_fail(FR_EINVAL, "fr_fisher_workspace_layout: bad argument");
+	const FrFisherLayout L = fr_fisher_layout(P, W, H, n_views, max_rendered, columns);
+	o[0] = L.tile_cnt; o[1] = L.tile_off; o[2] = L.keys; o[3] = L.splat; o[4] = L.recq; o[5] = L.tile_scores; o[6] = L.status; o[7] = L.vis_n;
+	return FR_OK;
+}
+
+extern "C" int fr_init(void)
+{
+	if (!fr_side_stream(0).ok || !fr_side_stream(1).ok) return fr_fail(FR_ELAUNCH, "fr_init: could not create the side streams");
+	return FR_OK;
+}
+
 extern "C" size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns)
 {
 	if (P < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0 || (columns != 4 && columns != 11)) return 0;
 	return fr_fisher_layout(P, W, H, n_views, max_rendered, columns).total;
 }
 
+// score-only mode: the single front-to-back pass over the records (no capacity limit, no fallback kernel)
+static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipStream_t s)
+{
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (g_prof_on)
+	{
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, s);
+	}
+	hipLaunchKernelGGL(k_fisher_tile_v3, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	if (g_prof_on)
+	{
+		(void)hipEventRecord(ev1, s);
+		g_prof_events.push_back(std::make_pair(ev0, ev1));
+	}
+}
+
 template <int C>
-static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, float4* recq, bool list_mode, uint8_t* fallback, hipStream_t s)
+static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t* fallback, hipStream_t s)
 {
 	dim3 grid(p.T * p.V), block(FR_THREADS);
 	const bool hi = f.H_inv != nullptr, ho = f.out_H != nullptr;
@@ -3266,26 +3369,6 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, float4*
 	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed);
 	// measurement hook: events around the dominant kernel only, on the stream it runs on
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	if (hi && !ho && !f.dL_img && f.debug_mode != 1 && f.debug_mode != 9)      // FR_DEBUG_MODE=9: second-generation kernel (A/B)
-	{
-		// score-only: per-(view, Gaussian) records once, then the single front-to-back pass (no capacity limit, no fallback)
-		const int per_block = FR_THREADS * p.G;
-		dim3 gridP((p.P + per_block - 1) / per_block, p.V);
-		if (list_mode) hipLaunchKernelGGL((k_fisher_records<C, true>), gridP, block, 0, s, p, f, (const float*)packed, recq);
-		else hipLaunchKernelGGL((k_fisher_records<C, false>), gridP, block, 0, s, p, f, (const float*)packed, recq);
-		if (g_prof_on)
-		{
-			(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
-			(void)hipEventRecord(ev0, s);
-		}
-		hipLaunchKernelGGL(k_fisher_tile_v3, grid, block, 0, s, p, f, (const float4*)recq);
-		if (g_prof_on)
-		{
-			(void)hipEventRecord(ev1, s);
-			g_prof_events.push_back(std::make_pair(ev0, ev1));
-		}
-		return;
-	}
 	if (g_prof_on)
 	{
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
@@ -3351,8 +3434,6 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	p.key_capacity = max_rendered;
 	p.vis_count = fc->out_vis_count;
 	p.num_rendered = fc->out_num_rendered;
-	if ((rc = fr_bin_pipeline(p, g, s))) return rc;
-
 	FrFisherArgs f;
 	f.dL = fc->dL_dpix;
 	f.dL_img = fc->dL_dpix_image; f.dL_stride = fc->dL_image_view_stride;
@@ -3360,10 +3441,19 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.out_H = fc->out_H; f.outH_stride = fc->out_H_view_stride;
 	f.tile_scores = (float*)(ws + L.tile_scores);
 	f.only_flagged = nullptr;
-	{ const char* dm = getenv("FR_DEBUG_MODE"); f.debug_mode = dm ? atoi(dm) : 0; }
-	const bool list_mode = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;     // the front end fr_bin_pipeline picked
-	if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (float4*)(ws + L.recq), list_mode, (uint8_t*)(ws + L.fallback), s);
-	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (float4*)(ws + L.recq), list_mode, (uint8_t*)(ws + L.fallback), s);
+	f.debug_mode = fr_debug_mode();
+	// score-only (H_inv, no out_H, constant upstream gradient): records + one front-to-back pass; FR_DEBUG_MODE=9 keeps
+	// the second-generation two-pass kernel for A/B runs
+	const bool v3 = fc->H_inv && !fc->out_H && !fc->dL_dpix_image && f.debug_mode != 1 && f.debug_mode != 9;
+	FrScorerPlan plan;
+	plan.columns = fc->columns;
+	plan.ra.H_inv = fc->H_inv; plan.ra.hinv_stride = fc->H_inv_view_stride;
+	plan.ra.packed = (const float*)(ws + L.packed); plan.ra.recq = (float4*)(ws + L.recq);
+	if ((rc = fr_bin_pipeline(p, g, s, v3 ? &plan : nullptr))) return rc;
+
+	if (v3) fr_launch_fisher_v3(p, f, plan.ra.recq, s);
+	else if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
+	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
 
 	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
 	if (fc->out_scores)

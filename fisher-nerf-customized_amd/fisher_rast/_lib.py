@@ -79,13 +79,29 @@ class OccCfg(ctypes.Structure):
 
 # every symbol include/fisher_rast.h and include/fisher_occ.h declare
 EXPORTS = (
-    "fr_version", "fr_last_error", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
+    "fr_version", "fr_last_error", "fr_build_id", "fr_init", "fr_fisher_workspace_layout", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
     "fr_forward", "fr_backward", "fr_forward_pair", "fr_forward_features", "fr_backward_pair", "fr_fisher_workspace_bytes", "fr_fisher_views",
     "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
     "fr_occ_workspace_bytes", "fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of",
 )
 
 _lib = None
+
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+_INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include")
+SOURCES = [os.path.join(_CSRC, n) for n in ("fisher_rast.hip", "fisher_occ.hip", "fr_math.h", "fr_internal.h")] + \
+          [os.path.join(_INCLUDE, n) for n in ("fisher_rast.h", "fisher_occ.h")]
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel and header sources, or None when they are not beside the package."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES:
+        if not os.path.exists(f):
+            return None
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 class FisherRastError(RuntimeError):
@@ -111,6 +127,17 @@ def load():
             raise FisherRastError(f"{SO_PATH} does not export {name}")
     lib.fr_version.restype = ctypes.c_int
     lib.fr_last_error.restype = ctypes.c_char_p
+    lib.fr_build_id.restype = ctypes.c_char_p
+    lib.fr_init.restype = ctypes.c_int
+    lib.fr_fisher_workspace_layout.restype = ctypes.c_int
+    lib.fr_fisher_workspace_layout.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]
+    # a stale or foreign binary must not pass for the sources beside it (FISHER_RAST_SO builds for A/B runs are exempt)
+    want = source_hash()
+    got = lib.fr_build_id().decode().split(":")[-1]
+    if "FISHER_RAST_SO" not in os.environ and want is not None and got != want:
+        raise FisherRastError(f"{SO_PATH} was built from other sources (build id {got}, sources {want}): "
+                              "run `python -c \"import __graft_entry__ as g; g.build()\"`")
     lib.fr_workspace_bytes.restype = ctypes.c_int
     lib.fr_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                        ctypes.POINTER(ctypes.c_size_t)]

@@ -7,7 +7,10 @@
  *
  * Every entry point
  *   - takes plain device pointers and sizes (no torch types), plus an explicit HIP stream;
- *   - never allocates, never synchronises the device, never throws;
+ *   - never allocates device memory, never synchronises the device, never throws.  The forward / scorer pipelines
+ *     fork onto two internal side streams (sort tier, scorer records) and join back onto the caller's stream; those
+ *     two streams and four timing-disabled events are created once per host thread and device, by fr_init() or
+ *     lazily by the first call that needs them (fr_profile_enable(1) additionally records two events per launch);
  *   - returns 0 on success or an FR_E* code; fr_last_error() gives the message (thread-local).
  *
  * Reference interfaces replaced (paths relative to the reference tree,
@@ -84,6 +87,11 @@ typedef struct fr_gaussians {
 
 int fr_version(void);
 const char* fr_last_error(void);
+/* Hash of the kernel / header sources this library was compiled from (stamped by __graft_entry__.build();
+ * "unstamped" for a hand build).  The Python loader refuses a library whose id does not match the sources beside it. */
+const char* fr_build_id(void);
+/* Optional: creates the calling thread's side streams and events for the current device now instead of on first use. */
+int fr_init(void);
 
 /* ---- single-view rasteriser (the reference's _C.rasterize_gaussians / _backward / mark_visible) ---- */
 
@@ -167,6 +175,12 @@ typedef struct fr_fisher_cfg {
 } fr_fisher_cfg;
 
 size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);
+/* Byte offsets of the named sections inside the scorer's workspace (for tests / debuggers):
+ * [0] tile_count u32[V,T], [1] tile_offset u32[V,T], [2] keys u64[R] (sorted per (view, tile): (depth_bits << 32) | gaussian_index),
+ * [3] per-(view, Gaussian) 32-byte records [V,P] (valid where visible), [4] per-(view, Gaussian) 64-byte scorer records [V,P],
+ * [5] tile_scores f32[V,T], [6] status i32[4], [7] visible-list lengths u32[V, blocks] */
+int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns,
+                               size_t offsets[8]);
 
 /* Scores n_views candidate poses in one batched launch sequence.  g->means3D are WORLD positions; each view's
  * camera-frame means are computed in-kernel from cfg_f->w2c and then rendered through cfg->viewmatrix/projmatrix
@@ -187,7 +201,7 @@ int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, si
 /* ---- measurement hooks (not part of the reference surface) ------------------------------------------ */
 
 /* When enabled, every fr_fisher_views call records a pair of HIP events around its dominant kernel
- * (k_fisher_tile_v2) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
+ * (k_fisher_tile_v3 in the score-only mode, k_fisher_tile_v2 otherwise) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
 int fr_profile_enable(int on);
 /* Waits for the recorded events and writes up to max_n per-launch durations in milliseconds; returns the count
  * (or -1 on a HIP error).  This is the only entry point that blocks. */
