@@ -1535,7 +1535,8 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 			fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
 			float A[3][5];
 			float B[6][3];
-			fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr);
+			// IEEE division in the modes that materialise cur_H (1e-4 per element, near-plane splats included); reciprocals when only a sum is wanted
+			fr_mean_jacobian<!HAS_OUTH>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr);
 			// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
 			// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
 			float Ap[3][5];
