@@ -462,6 +462,106 @@ __global__ __launch_bounds__(OCC_THREADS) void k_occ_cells_of(OccGeom g, const f
 	cells[2 * (size_t)i + 1] = occ_bin(xyz[3 * (size_t)i + 2], g.cz, g.cell, g.gh);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Candidate samplers (astar.py:1406-1430 / 1432-1469 generate_candidate[_object]; 1387-1401 free-space filter;
+// 782-837 sample_random_candidate).  The reference draws from torch / numpy generators on the host; here the draws come
+// from a counter-based generator so that a call is a pure function of (seed, index) and has a NumPy restatement
+// (oracle/occupancy_frontier.py: occ_uniform):  x = seed + 0x9E3779B9 (4 k + j + 1), then the 32-bit finaliser
+// x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16;  u = (x >> 8) / 2^24  in [0, 1).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float occ_uniform(uint32_t seed, uint32_t k, uint32_t j)
+{
+	uint32_t x = seed + 0x9E3779B9u * (4u * k + j + 1u);
+	x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+	return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// rotation about y from the quaternion (qr, 0, qy, 0) exactly as build_rotation does it (slam_external.py:25-42:
+// normalise, then the 3x3 entries), written into rows 0..2 of a row-major 4x4 whose other entries are already set
+__device__ __forceinline__ void occ_yaw_rotation(float qr, float qy, float* __restrict__ m, float s0, float s1, float s2)
+{
+	const float norm = sqrtf(qr * qr + qy * qy);
+	const float r = qr / norm, y = qy / norm;
+	const float d = 1.0f - 2.0f * (y * y), o = 2.0f * (r * y);
+	// R = [[d, 0, o], [0, 1, 0], [-o, 0, d]]; s0..s2 are the column signs the caller applies afterwards
+	m[0] = d * s0;  m[1] = 0.0f * s1; m[2] = o * s2;
+	m[4] = 0.0f * s0; m[5] = 1.0f * s1; m[6] = 0.0f * s2;
+	m[8] = -o * s0; m[9] = 0.0f * s1; m[10] = d * s2;
+}
+
+__global__ __launch_bounds__(1024) void k_occ_ring_candidates(OccGeom g, const float* __restrict__ centers, int n_centers, int K,
+                                                              float min_range, float radius, float cam_height, uint32_t seed,
+                                                              const uint8_t* __restrict__ eroded, int min_free,
+                                                              float* __restrict__ c2w, uint8_t* __restrict__ keep)
+{
+	__shared__ unsigned long long s_free;
+	const int tid = threadIdx.x;
+	if (tid == 0) s_free = 0ull;
+	__syncthreads();
+	if (eroded)
+	{
+		// astar.py:1389: the filter applies only when the eroded free space has more than `min_free` cells
+		unsigned long long c = 0;
+		const size_t n = (size_t)g.gw * g.gh;
+		for (size_t i = tid; i < n; i += 1024) c += eroded[i] ? 1ull : 0ull;
+		if (c) atomicAdd(&s_free, c);
+	}
+	__syncthreads();
+	const bool filter = eroded != nullptr && s_free > (unsigned long long)min_free;
+	const float pi = 3.14159274101257324f;                     // torch.pi as float32
+	for (int k = tid; k < K; k += 1024)
+	{
+		const float theta = (occ_uniform(seed, (uint32_t)k, 0) * 2.0f) * pi;
+		const float rr = min_range + occ_uniform(seed, (uint32_t)k, 1) * (radius - min_range);
+		int ci = (int)(occ_uniform(seed, (uint32_t)k, 2) * (float)n_centers);
+		ci = ci > n_centers - 1 ? n_centers - 1 : ci;
+		const float px = centers[2 * (size_t)ci] + rr * sinf(theta);
+		const float pz = centers[2 * (size_t)ci + 1] + rr * cosf(theta);
+		float* m = c2w + 16 * (size_t)k;
+		const float phi = theta + pi;
+		occ_yaw_rotation(cosf(phi / 2.0f), sinf(phi / 2.0f), m, -1.0f, -1.0f, 1.0f);   // astar.py:1419-1420: columns 0 and 1 negated
+		m[3] = px; m[7] = cam_height; m[11] = pz;
+		m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+		if (keep)
+		{
+			uint8_t kp = 1;
+			if (filter)
+			{
+				// astar.py:1392-1398: (x - map_center) / cell_size + grid_dim // 2, .long() (truncation), eroded[row, col]
+				const long long col = (long long)((px - g.cx) / g.cell + (float)(g.gw / 2));
+				const long long row = (long long)((pz - g.cz) / g.cell + (float)(g.gh / 2));
+				kp = (col >= 0 && col < g.gw && row >= 0 && row < g.gh) ? (eroded[(size_t)row * g.gw + col] ? 1 : 0) : 0;
+			}
+			keep[k] = kp;
+		}
+	}
+}
+
+__global__ __launch_bounds__(OCC_THREADS) void k_occ_free_candidates(OccGeom g, const int* __restrict__ cells, const int* __restrict__ counts,
+                                                                     float agent_y, uint32_t seed, float* __restrict__ c2w, int max_out,
+                                                                     int* __restrict__ n_out)
+{
+	const int n_free = counts[0];
+	int m_out = n_free / 4;                                    // astar.py:813: rng.choice(len, len // 4)
+	m_out = m_out > max_out ? max_out : m_out;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = m_out;
+	for (int i = blockIdx.x * OCC_THREADS + threadIdx.x; i < m_out; i += gridDim.x * OCC_THREADS)
+	{
+		int ci = (int)(occ_uniform(seed, (uint32_t)i, 0) * (float)n_free);
+		ci = ci > n_free - 1 ? n_free - 1 : ci;
+		const int col = cells[2 * (size_t)ci], row = cells[2 * (size_t)ci + 1];
+		// astar.py:808-810, in double like numpy, narrowed once
+		const float wx = (float)(((double)col + 0.5 - (double)(g.gw / 2)) * (double)g.cell + (double)g.cx);
+		const float wz = (float)(((double)row + 0.5 - (double)(g.gh / 2)) * (double)g.cell + (double)g.cz);
+		const double ang = (double)occ_uniform(seed, (uint32_t)i, 1) * 6.283185307179586;
+		float* m = c2w + 16 * (size_t)i;
+		occ_yaw_rotation((float)cos(ang / 2.0), (float)sin(ang / 2.0), m, 1.0f, -1.0f, -1.0f);   // astar.py:833-834: columns 1 and 2 negated
+		m[3] = wx; m[7] = agent_y; m[11] = wz;
+		m[12] = 0.f; m[13] = -0.f; m[14] = -0.f; m[15] = 1.f;
+	}
+}
+
 // =========================================================================================================
 // host side
 // =========================================================================================================
@@ -664,4 +764,40 @@ extern "C" int fr_occ_cells_of(const fr_occ_cfg* cfg, const float* xyz, int32_t 
 	if (n == 0) return FR_OK;
 	hipLaunchKernelGGL(k_occ_cells_of, occ_grid((size_t)n), dim3(OCC_THREADS), 0, (hipStream_t)stream, occ_geom(cfg), xyz, n, cells);
 	return fr_check_launch("fr_occ_cells_of");
+}
+
+extern "C" int fr_occ_ring_candidates(const fr_occ_cfg* cfg, const float* centers, int32_t n_centers, int32_t K,
+                                      float min_range, float radius, float cam_height, uint32_t seed,
+                                      const uint8_t* eroded_free, int32_t min_free, float* c2w, uint8_t* keep, fr_stream_t stream)
+{
+	int rc = occ_validate(cfg, "fr_occ_ring_candidates");
+	if (rc) return rc;
+	if (K < 0 || n_centers < 0 || (K > 0 && (!centers || n_centers == 0 || !c2w))) return fr_fail(FR_EINVAL, "fr_occ_ring_candidates: bad argument");
+	if (K == 0) return FR_OK;
+	hipLaunchKernelGGL(k_occ_ring_candidates, dim3(1), dim3(1024), 0, (hipStream_t)stream, occ_geom(cfg), centers, n_centers, K,
+	                   min_range, radius, cam_height, seed, eroded_free, min_free, c2w, keep);
+	return fr_check_launch("fr_occ_ring_candidates");
+}
+
+extern "C" int fr_occ_free_candidates(const fr_occ_cfg* cfg, const uint8_t* eroded_free, float agent_y, uint32_t seed,
+                                      float* c2w, int32_t max_out, int32_t* counts, void* workspace, size_t workspace_bytes,
+                                      fr_stream_t stream)
+{
+	int rc = occ_validate(cfg, "fr_occ_free_candidates");
+	if (rc) return rc;
+	if (!eroded_free || !counts || max_out < 0 || (max_out > 0 && !c2w)) return fr_fail(FR_EINVAL, "fr_occ_free_candidates: bad argument");
+	const OccLayout L = occ_layout(cfg);
+	if (!workspace || workspace_bytes < L.total) return fr_fail(FR_ENOSPACE, "fr_occ_free_candidates: workspace smaller than fr_occ_workspace_bytes()");
+	hipStream_t s = (hipStream_t)stream;
+	char* ws = (char*)workspace;
+	const OccGeom g = occ_geom(cfg);
+	int* rows = (int*)(ws + L.rows);
+	int* cells = (int*)(ws + L.dist);                          // n * 8 bytes: one (col, row) pair per cell
+	hipLaunchKernelGGL(k_row_count, dim3(g.gh), dim3(OCC_THREADS), 0, s, g, eroded_free, rows);
+	hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, s, g.gh, rows, counts);
+	hipLaunchKernelGGL(k_row_emit, dim3(g.gh), dim3(64), 0, s, g, eroded_free, (const int*)rows, cells, g.gw * g.gh);
+	const int blocks = max_out > 0 ? (max_out + OCC_THREADS - 1) / OCC_THREADS : 1;
+	hipLaunchKernelGGL(k_occ_free_candidates, dim3(blocks > 1024 ? 1024 : blocks), dim3(OCC_THREADS), 0, s, g, (const int*)cells,
+	                   (const int*)counts, agent_y, seed, c2w, max_out, counts + 1);
+	return fr_check_launch("fr_occ_free_candidates");
 }

@@ -83,6 +83,7 @@ EXPORTS = (
     "fr_forward", "fr_backward", "fr_forward_pair", "fr_forward_features", "fr_backward_pair", "fr_fisher_workspace_bytes", "fr_fisher_views",
     "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
     "fr_occ_workspace_bytes", "fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of",
+    "fr_occ_ring_candidates", "fr_occ_free_candidates",
 )
 
 _lib = None
@@ -196,6 +197,12 @@ def load():
                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.fr_occ_erode.restype = ctypes.c_int
     lib.fr_occ_erode.argtypes = [occp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.fr_occ_ring_candidates.restype = ctypes.c_int
+    lib.fr_occ_ring_candidates.argtypes = [occp, _f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                           ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int32, _f32p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_occ_free_candidates.restype = ctypes.c_int
+    lib.fr_occ_free_candidates.argtypes = [occp, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint32, _f32p, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.fr_occ_cells_of.restype = ctypes.c_int
     lib.fr_occ_cells_of.argtypes = [occp, _f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     _lib = lib

@@ -10,32 +10,33 @@ import torch
 NON_PARAM_KEYS = ("Uncertainty", "occ_map")     # tester 2750: extras stored beside the parameters
 
 
+def _as_numpy(value):
+    """Tensors go to host memory as contiguous arrays; anything else is stored as it is (np.savez wraps it)."""
+    return value.detach().cpu().contiguous().numpy() if isinstance(value, torch.Tensor) else value
+
+
+def _write_checkpoint(params, output_dir, stem, extras=None):
+    """One `.npz` with an array per parameter name, plus the caller's extra arrays under their keyword names."""
+    os.makedirs(output_dir, exist_ok=True)
+    arrays = {name: _as_numpy(v) for name, v in params.items()}
+    arrays.update({name: _as_numpy(v) for name, v in (extras or {}).items()})
+    path = os.path.join(output_dir, stem + ".npz")
+    np.savez(path, **arrays)
+    return path
+
+
 def params2cpu(params):
-    res = {}
-    for k, v in params.items():
-        if isinstance(v, torch.Tensor):
-            res[k] = v.detach().cpu().contiguous().numpy()
-        else:
-            res[k] = v
-    return res
+    return {name: _as_numpy(v) for name, v in params.items()}
 
 
 def save_params(output_params, output_dir):
-    to_save = params2cpu(output_params)
-    os.makedirs(output_dir, exist_ok=True)
-    save_path = os.path.join(output_dir, "params.npz")
-    np.savez(save_path, **to_save)
-    return save_path
+    """The final map: `<output_dir>/params.npz` (common_utils.py:35-43)."""
+    return _write_checkpoint(output_params, output_dir, "params")
 
 
 def save_params_ckpt(output_params, output_dir, time_idx, **extra_args):
-    to_save = params2cpu(output_params)
-    os.makedirs(output_dir, exist_ok=True)
-    save_path = os.path.join(output_dir, "params" + str(time_idx) + ".npz")
-    for k, v in extra_args.items():
-        to_save[k] = v.cpu().numpy() if isinstance(v, torch.Tensor) else v
-    np.savez(save_path, **to_save)
-    return save_path
+    """A checkpoint of frame `time_idx`: `<output_dir>/params<time_idx>.npz` (common_utils.py:45-59)."""
+    return _write_checkpoint(output_params, output_dir, f"params{time_idx}", extra_args)
 
 
 def checkpoint_time_idx(weight_file):

@@ -12,6 +12,9 @@
  *                           (dilate - free AND unknown, dilate, components, min area 10, largest / combined / closest)
  *   fr_occ_erode         <- cv2.erode(free_space, np.ones((k, k)))  planning/astar.py:805, 1388
  *   fr_occ_cells_of      <- datasets/util/map_utils.py:106-125 discretize_coords
+ *   fr_occ_ring_candidates <- AstarPlanner.generate_candidate / generate_candidate_object planning/astar.py:1383-1430, 1432-1469
+ *                           fused with the free-space filter of the candidate loop planning/astar.py:1387-1401
+ *   fr_occ_free_candidates <- AstarPlanner.sample_random_candidate   planning/astar.py:782-837
  *
  * Conventions are fisher_rast.h's: device pointers unless noted, explicit stream, no allocation, no device
  * synchronisation, 0 or an FR_E* code, message through fr_last_error().
@@ -69,6 +72,24 @@ int fr_occ_erode(const fr_occ_cfg* cfg, const uint8_t* src, uint8_t* dst, int32_
 
 /* discretize_coords for n (x, z) pairs taken from xyz[n][3] (columns 0 and 2): cells[n][2] = (col, row), int32 */
 int fr_occ_cells_of(const fr_occ_cfg* cfg, const float* xyz, int32_t n, int32_t* cells, fr_stream_t stream);
+
+/* Candidate poses on a ring around centres drawn (with replacement) from `centers` [n_centers][2] = (x, z):
+ * position = centre + r (sin t, 0, cos t) at height cam_height, t = 2 pi u0, r = min_range + u1 (radius - min_range),
+ * centre index = floor(u2 n_centers); orientation = yaw (t + pi) with columns 0 and 1 negated (astar.py:1406-1423).
+ * The uniforms come from a counter-based generator keyed by (seed, k): see occ_uniform in fisher_occ.hip, restated in
+ * oracle/occupancy_frontier.py.  c2w: [K][16] row-major, out.  keep: [K] uint8 out or null -- 1 where the pose's cell lies in
+ * `eroded_free` (uint8 [grid_h][grid_w], or null = keep all); as in the reference the filter only applies when more
+ * than `min_free` cells of eroded_free are set (astar.py:1389: 40). */
+int fr_occ_ring_candidates(const fr_occ_cfg* cfg, const float* centers, int32_t n_centers, int32_t K,
+                           float min_range, float radius, float cam_height, uint32_t seed,
+                           const uint8_t* eroded_free, int32_t min_free, float* c2w, uint8_t* keep, fr_stream_t stream);
+
+/* Uniformly placed poses in the (already eroded) free space: the free cells in raster order, a quarter as many draws with
+ * replacement, position at the cell centre and height agent_y, uniform yaw with columns 1 and 2 negated (astar.py:805-835).
+ * c2w: [max_out][16] out; counts: device int32[2] = {free cells, poses written}. */
+int fr_occ_free_candidates(const fr_occ_cfg* cfg, const uint8_t* eroded_free, float agent_y, uint32_t seed,
+                           float* c2w, int32_t max_out, int32_t* counts, void* workspace, size_t workspace_bytes,
+                           fr_stream_t stream);
 
 #ifdef __cplusplus
 }

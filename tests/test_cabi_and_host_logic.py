@@ -193,8 +193,9 @@ def test_install_grafts_methods_onto_reference_like_classes():
     FisherOps.install(RefSLAM)
     assert RefSLAM.FISHER_COLUMNS == 4 and all(callable(getattr(RefSLAM, n)) for n in ("compute_Hessian", "compute_H_train", "pose_eval", "path_scores"))
     ObjectFisherOps.install(RefObjectSLAM)
-    assert RefObjectSLAM.FISHER_COLUMNS == 11 and RefObjectSLAM._DIAG_ORDER[0] == (0, 3)
+    assert RefObjectSLAM.FISHER_COLUMNS == 11 and callable(RefObjectSLAM._flat_diag)
     assert all(callable(getattr(RefObjectSLAM, n)) for n in ("pose_eval", "estimate_diag_JtJ_simple", "estimate_block_JtJ", "pose_eval_popgs", "pose_eval_popgs_blocks"))
     assert RefObjectSLAM().topt_score_from_diags() == 1                       # the reference's own helpers are left alone
     OccupancyOps.install(RefPlanner)
-    assert all(callable(getattr(RefPlanner, n)) for n in ("update_occ_map", "build_connected_freespace", "build_frontiers", "generate_candidate"))
+    assert all(callable(getattr(RefPlanner, n)) for n in ("update_occ_map", "build_connected_freespace", "build_frontiers", "generate_candidate",
+                                                                   "generate_candidate_object", "generate_candidate_in_freespace", "sample_random_candidate"))

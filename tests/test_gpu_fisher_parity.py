@@ -179,6 +179,25 @@ def test_per_view_weights_path_eval(config1, gpu):
         assert one[0] == got[v]
 
 
+def _autograd_probe_rows(slam, w2c, zs):
+    """The reference's route for one pose (gaussian_object.py:2066-2098): one forward of the drop-in autograd rasteriser with
+    backward_power=2, then one backward per upstream draw.  Returns ([K] rows [N,11] ordered [mean|opacity|rot|scale], radius)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from models.SLAM.utils.slam_helpers import transformed_params2rendervar
+    pts = slam.params["means3D"]
+    tp = (w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3].contiguous()
+    rv = {k: (v.detach().clone().requires_grad_(True) if k != "means2D" else v) for k, v in transformed_params2rendervar(slam.params, tp).items()}
+    im, radius, _ = GaussianRasterizer(raster_settings=slam.cam, backward_power=2)(**rv)
+    out = []
+    for k, z in enumerate(zs):
+        for t in rv.values():
+            if t.is_leaf:
+                t.grad = None
+        im.backward(gradient=z.to(im.device), retain_graph=k + 1 < len(zs))
+        out.append(torch.cat([rv["means3D"].grad, rv["opacities"].grad.reshape(-1, 1), rv["rotations"].grad, rv["scales"].grad], 1).clone())
+    return out, radius
+
+
 def test_popgs_diag_estimator(config1, gpu, oracle):
     """estimate_diag_JtJ_simple (gaussian_object.py:2049-2109) with the random upstream gradients supplied:
     diag = mean_k (power-2 gradient under z_k)^2, layout [means | opacity | rot | scale]."""
@@ -190,7 +209,10 @@ def test_popgs_diag_estimator(config1, gpu, oracle):
     zs = [torch.randn((3, c["H"], c["W"]), generator=g) for _ in range(K)]
     w2c = torch.linalg.inv(c["c2w"][1].to(gpu))
     diag, vis = slam.estimate_diag_JtJ_simple(w2c, K=K, zs=zs)                  # fused: all probes in one fr_fisher_views launch
-    diag_ag, vis_ag = slam.estimate_diag_JtJ_simple(w2c, K=K, zs=zs, fused=False)   # the reference's autograd route
+    rows_ag, radius = _autograd_probe_rows(slam, w2c, zs)                        # the reference's autograd route
+    sq = sum(r * r for r in rows_ag) / K
+    diag_ag = torch.cat([sq[:, 0:3].reshape(-1), sq[:, 3:4].reshape(-1), sq[:, 4:8].reshape(-1), sq[:, 8:11].reshape(-1)])
+    vis_ag = int((radius > 0).sum())
     P = c["P"]
     assert diag.shape == (P * 11,) and vis == vis_ag
     assert_close(diag.cpu().numpy(), diag_ag.double().cpu().numpy(), 2e-4, "diag_JtJ fused vs autograd", atol_frac=1e-7)
@@ -232,7 +254,9 @@ def test_popgs_block_estimator(config1, gpu, oracle):
     zs = [torch.randn((3, c["H"], c["W"]), generator=g) for _ in range(K)]
     w2c = torch.linalg.inv(c["c2w"][2].to(gpu))
     Hb, vis_idx = slam.estimate_block_JtJ(w2c, K=K, zs=zs)                       # fused route
-    Hb_ag, vis_ag = slam.estimate_block_JtJ(w2c, K=K, zs=zs, fused=False)         # autograd route
+    rows_ag, radius = _autograd_probe_rows(slam, w2c, zs)                         # autograd route
+    vis_ag = torch.nonzero(radius > 0).reshape(-1)
+    Hb_ag = sum(r[vis_ag].unsqueeze(2) * r[vis_ag].unsqueeze(1) for r in rows_ag) / K
     assert torch.equal(vis_idx, vis_ag)
     assert_close(Hb.cpu().numpy(), Hb_ag.double().cpu().numpy(), 4e-4, "block_JtJ fused vs autograd", atol_frac=1e-7)
     from models.SLAM.utils.slam_helpers import transformed_params2rendervar

@@ -104,16 +104,60 @@ def test_erode_cells_and_candidate_filter(gpu):
     cells = pl.cells_of(xyz.to(gpu)).cpu().numpy()
     want = discretize_coords(xyz[:, 0].numpy(), xyz[:, 2].numpy(), (768, 768), 0.05, (0.0, 0.0))
     assert np.array_equal(cells, want)
-    # candidate poses: same construction as the reference, then the eroded-free-space filter
-    pl.cam_height = 0.0
-    torch.manual_seed(3)
-    cand = pl.generate_candidate(torch.from_numpy(poses[:, [0, 2], 3]).to(gpu), expansion=1)      # around the observed camera positions
-    assert cand.shape == (pl.K, 4, 4) and torch.allclose(cand[:, :3, :3] @ cand[:, :3, :3].transpose(1, 2), torch.eye(3, device=gpu).expand(pl.K, 3, 3), atol=1e-5)
-    kept = pl.filter_candidates_in_freespace(cand, free)
-    er = ndimage.binary_erosion(free.astype(bool), structure=np.ones((10, 10), bool), border_value=1)
-    xy = cand[:, [0, 2], 3].cpu().numpy()
-    cx = ((xy[:, 0] - 0.0) / 0.05 + 768 // 2).astype(np.int64); cz = ((xy[:, 1] - 0.0) / 0.05 + 768 // 2).astype(np.int64)
-    assert kept.shape[0] == int(er[cz, cx].sum()) and 0 < kept.shape[0] <= pl.K
+
+
+def test_candidate_samplers_match_the_restatement(gpu):
+    """fr_occ_ring_candidates (generate_candidate[_object] + the free-space filter, astar.py:1383-1430) and
+    fr_occ_free_candidates (sample_random_candidate, astar.py:782-837) against oracle/occupancy_frontier.py on the same seed:
+    poses within float32 rounding of sin / cos (1e-6), the keep flags and the pose count exact."""
+    from scipy import ndimage
+    from oracle.occupancy_frontier import ring_candidates, free_candidates
+    pl, om, poses, depths = _setup(gpu, 128, 128, 768, 6, 303)
+    for t, (p, d) in enumerate(zip(poses, depths)):
+        pl.update_occ_map(d, torch.from_numpy(p).to(gpu), t)
+    free = pl.build_connected_freespace(None)
+    pl.cam_height = 0.25
+    centers = torch.from_numpy(poses[:, [0, 2], 3]).to(gpu)                 # around the observed camera positions
+    for K, seed, expansion in ((64, 1234, 1.0), (257, 99, 1.5), (1500, 7, 2.25)):
+        pl.K = K
+        cand = pl.generate_candidate(centers, expansion=expansion, seed=seed)
+        want, _ = ring_candidates(centers.cpu().numpy(), K, pl.min_range, pl.radius * expansion, pl.cam_height, seed)
+        assert cand.shape == (K, 4, 4)
+        assert np.abs(cand.cpu().numpy() - want).max() < 2e-6
+        R = cand[:, :3, :3]
+        assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, device=gpu).expand(K, 3, 3), atol=1e-5)
+        # fused filter: flags from the restatement evaluated on the GPU's own positions (so a last-bit difference in sin / cos cannot flip a cell)
+        er = ndimage.binary_erosion(free.astype(bool), structure=np.ones((10, 10), bool), border_value=1)
+        kept = pl.generate_candidate_in_freespace(centers, free, expansion=expansion, seed=seed)
+        xy = cand[:, [0, 2], 3].cpu().numpy()
+        col = ((xy[:, 0] - np.float32(0.0)) / np.float32(0.05) + np.float32(384)).astype(np.int64)
+        row = ((xy[:, 1] - np.float32(0.0)) / np.float32(0.05) + np.float32(384)).astype(np.int64)
+        keep = er[row, col]
+        assert er.sum() > 40 and 0 < keep.sum() < K
+        assert torch.equal(kept, cand[torch.from_numpy(keep).to(gpu)])
+        assert torch.equal(pl.filter_candidates_in_freespace(cand, free), kept)
+        _, keep_o = ring_candidates(centers.cpu().numpy(), K, pl.min_range, pl.radius * expansion, pl.cam_height, seed, eroded=er)
+        assert (keep_o != keep).sum() <= 1                                   # the restatement's own positions: at most a boundary case
+    # the object ring uses its own parameters
+    pl.K_object, pl.radius_object, pl.min_range_object = 33, 0.8, 0.3
+    got = pl.generate_candidate_object(centers, expansion=2, seed=5)
+    want, _ = ring_candidates(centers.cpu().numpy(), 33, 0.3, 1.6, pl.cam_height, 5)
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-6
+    # a filter on an almost empty free space keeps everything (astar.py:1389)
+    few = np.zeros_like(free); few[380:386, 380:386] = 1
+    assert pl.generate_candidate_in_freespace(centers, few, seed=3).shape[0] == pl.K
+    # torch.manual_seed makes the default seeding reproducible
+    torch.manual_seed(3); a = pl.generate_candidate(centers)
+    torch.manual_seed(3); b = pl.generate_candidate(centers)
+    assert torch.equal(a, b) and not torch.equal(a, pl.generate_candidate(centers))
+    # uniformly placed poses in the free space
+    rp = pl.sample_random_candidate(np.array([0.0, 0.4, 0.0]), free, seed=77)
+    er11 = ndimage.binary_erosion(free.astype(bool), structure=np.ones((11, 11), bool), border_value=1).astype(np.uint8)
+    want = free_candidates(er11, 0.4, 77)
+    assert rp.shape == want.shape and rp.shape[0] == int(er11.sum()) // 4 > 100
+    assert np.abs(rp.cpu().numpy() - want).max() < 2e-6
+    xz = rp[:, [0, 2], 3].cpu().numpy()                                       # the planner's own cell rule (astar.py:93-94)
+    assert er11[(xz[:, 1] / 0.05 + 384).astype(np.int64), (xz[:, 0] / 0.05 + 384).astype(np.int64)].all()   # every pose sits in the eroded free space
 
 
 def test_bad_arguments_are_reported(gpu):
