@@ -27,11 +27,18 @@ def _world(group=None):
     return 0, 1
 
 
+def _host_collectives(t: torch.Tensor, group=None) -> bool:
+    """gloo (the CPU rehearsal backend) is driven with host tensors; nccl (RCCL) takes the device tensors as they are."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def gather_scores(local_scores: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """All-gather of per-view scores from contiguous shards of possibly unequal length -> [n_total] on every rank."""
     rank, world = _world(group)
     if world == 1:
         return local_scores
+    if _host_collectives(local_scores, group):
+        return gather_scores(local_scores.cpu(), n_total, group).to(local_scores.device)
     per = (n_total + world - 1) // world
     buf = torch.zeros((per,), dtype=local_scores.dtype, device=local_scores.device)
     buf[: local_scores.numel()] = local_scores
@@ -66,8 +73,34 @@ def sharded_h_train(accumulate_fn: Callable[[torch.Tensor, torch.Tensor], None],
     if hi > lo:
         accumulate_fn(kf_w2c[lo:hi], H_train)
     if world > 1:
-        dist.all_reduce(H_train, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(H_train, dist.ReduceOp.SUM, group)
     return H_train
+
+
+def _all_reduce(t: torch.Tensor, op, group=None):
+    if _host_collectives(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def sharded_point_score_max(scorer, w2c_all: torch.Tensor, H_inv: torch.Tensor, group=None, chunk: int = 16) -> torch.Tensor:
+    """max over the candidate views of every Gaussian's score sum_c cur_H[v, i, c] * H_inv[i, c] -- the `max_points_score`
+    the reference keeps while it scans the candidates (gaussian.py:1284-1303).  Views sharded, ONE all-reduce(MAX) on [P]."""
+    rank, world = _world(group)
+    V = int(w2c_all.shape[0])
+    lo, hi = shard_bounds(V, rank, world)
+    best = torch.zeros((scorer.P,), dtype=torch.float32, device=w2c_all.device)       # the reference starts from zeros
+    for v0 in range(lo, hi, chunk):
+        w = w2c_all[v0:min(hi, v0 + chunk)]
+        cur = torch.zeros((int(w.shape[0]), scorer.P, scorer.columns), dtype=torch.float32, device=w2c_all.device)
+        scorer.run(w, out_H=cur, out_H_per_view=True)
+        best = torch.maximum(best, (cur * H_inv.unsqueeze(0)).sum(dim=2).max(dim=0).values)
+    if world > 1:
+        _all_reduce(best, dist.ReduceOp.MAX, group)
+    return best
 
 
 def pose_eval_sharded(scorer, kf_w2c: torch.Tensor, w2c_all: torch.Tensor, reg: float = 0.1, group=None):

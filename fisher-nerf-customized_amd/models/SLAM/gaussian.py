@@ -44,10 +44,26 @@ class FisherOps:
             m = torch.from_numpy(m)
         return m.to(self._device()).float()
 
+    _PARAM_KEYS = ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales')
+
+    def _scorer_key(self, extra):
+        """Identity + version of every tensor the scorer is built from: an in-place optimiser step bumps `_version`, a
+        densification / pruning pass replaces the tensors -- either way the key changes and the scorer is rebuilt."""
+        def sig(t):
+            return None if t is None else (id(t), t._version, t.data_ptr(), tuple(t.shape))
+        key = [sig(self.params.get(k, None)) for k in self._PARAM_KEYS] + [id(self.cam), self.FISHER_COLUMNS]
+        if extra is not None and extra is not False:
+            key += [sig(extra[k]) for k in ('means3D', 'rotations', 'opacity', 'scales')]
+        return tuple(key)
+
     def _scorer(self, extra=None):
-        """Activated render variables (gaussian.py:1529-1533) wrapped in a FisherScorer.  Rebuilt on every public
-        call because the map changes between planning rounds; `extra` appends random Gaussians
-        (gaussian_object.py:1971-1992)."""
+        """Activated render variables (gaussian.py:1529-1533) wrapped in a FisherScorer, with its packed inputs and workspace.
+        Kept between calls while the map is unchanged (the tester scores ~630 path steps per planning round on one map);
+        `extra` appends random Gaussians (gaussian_object.py:1971-1992)."""
+        key = self._scorer_key(extra)
+        cached = getattr(self, "_scorer_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         p = self.params
         with torch.no_grad():
             means = p['means3D'].detach()
@@ -65,7 +81,9 @@ class FisherOps:
                 op = torch.cat([op, extra['opacity'].to(dev).float().reshape(-1, 1)], dim=0)
                 sc = torch.cat([sc, extra['scales'].to(dev).float()], dim=0)
                 colors = torch.cat([colors, torch.full((extra['means3D'].shape[0], 3), 0.5, device=dev)], dim=0)
-        return FisherScorer(self.cam, means, colors, rot, op, sc, columns=self.FISHER_COLUMNS, dL_dpix=1e-3)
+        scorer = FisherScorer(self.cam, means, colors, rot, op, sc, columns=self.FISHER_COLUMNS, dL_dpix=1e-3)
+        self._scorer_cache = (key, scorer)
+        return scorer
 
     # -- reference surface ---------------------------------------------------------------------------
     def compute_Hessian(self, rel_w2c, return_points=False, random_gaussian_params=False, return_pose=False):
@@ -93,7 +111,7 @@ class FisherOps:
         """Sum of cur_H over the keyframes (gaussian.py:1338-1348), all keyframes in one batched call."""
         if len(self.keyframe_list) == 0:
             return None
-        scorer = self._scorer(random_gaussians if self.FISHER_COLUMNS == 11 else None)
+        scorer = self._scorer(random_gaussians if self.FISHER_COLUMNS == 11 else None)   # shared with pose_eval's scoring launch
         w2cs = torch.stack([self._as_w2c(kf['est_w2c']) for kf in self.keyframe_list])
         H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
         scorer.run(w2cs, out_H=H_train)
@@ -125,7 +143,7 @@ class FisherOps:
     @classmethod
     def install(cls, target_cls):
         """Graft the accelerated methods onto the reference's class."""
-        for name in ("_device", "_as_w2c", "_scorer", "compute_Hessian", "compute_H_train", "pose_eval", "path_scores"):
+        for name in ("_device", "_as_w2c", "_scorer", "_scorer_key", "_PARAM_KEYS", "compute_Hessian", "compute_H_train", "pose_eval", "path_scores"):
             setattr(target_cls, name, getattr(cls, name))
         if not hasattr(target_cls, "FISHER_COLUMNS"):
             target_cls.FISHER_COLUMNS = cls.FISHER_COLUMNS

@@ -43,14 +43,29 @@ def _worker(rank, world, port, V, K, out_dir):
             s, _ = ref.pose_eval(cam, w.numpy(), H_train.numpy(), *args)
             return torch.from_numpy(s).float()
 
+        n_points = P
+
+        class OracleScorer:                     # the slice of FisherScorer's surface that sharded_point_score_max uses
+            P, columns = n_points, 4
+
+            def run(self, w, out_H=None, out_H_per_view=False):
+                for i, m in enumerate(w):
+                    out_H[i] += torch.from_numpy(ref.compute_hessian(cam, m.numpy(), *args)[0])
+
+        best = D.sharded_point_score_max(OracleScorer(), w2c, H_inv, chunk=2)
         scores = D.sharded_scores(score, w2c)
         lo, hi = D.shard_bounds(V, rank, world)
         assert [c for c in calls if c[0] == "views"] == ([("views", hi - lo)] if hi > lo else [])
-        torch.save(dict(scores=scores, H_train=H_train, lo=lo, hi=hi), os.path.join(out_dir, f"r{rank}.pt"))
+        torch.save(dict(scores=scores, H_train=H_train, lo=lo, hi=hi, best=best), os.path.join(out_dir, f"r{rank}.pt"))
         if rank == 0:
             Hs = ref.compute_h_train(cam, kf.numpy(), *args)
             s, _ = ref.pose_eval(cam, w2c.numpy(), Hs, *args)
-            torch.save(dict(scores=torch.from_numpy(s).float(), H_train=torch.from_numpy(Hs)), os.path.join(out_dir, "serial.pt"))
+            # gaussian.py:1284-1303: running max over the views of the per-point score, starting from zeros
+            mx = torch.zeros((P,))
+            for m in w2c:
+                cur = torch.from_numpy(ref.compute_hessian(cam, m.numpy(), *args)[0])
+                mx = torch.maximum(mx, (cur * H_inv).sum(dim=1))
+            torch.save(dict(scores=torch.from_numpy(s).float(), H_train=torch.from_numpy(Hs), best=mx), os.path.join(out_dir, "serial.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -66,6 +81,7 @@ def test_sharded_pose_eval_world2(tmp_path, V, K):
     assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == ((0, 3, 3, 5) if V == 5 else (0, 1, 1, 1))
     assert torch.allclose(r0["H_train"], serial["H_train"], rtol=1e-5, atol=1e-12)
     assert torch.allclose(r0["scores"], serial["scores"], rtol=1e-5)
+    assert torch.equal(r0["best"], r1["best"]) and torch.equal(r0["best"], serial["best"])       # max is exact in any order
 
 
 def test_shard_bounds_partition():

@@ -166,6 +166,27 @@ def test_overflow_regrow_and_chunking(config1, gpu):
     assert rel_err(Ht2.cpu().numpy(), Ht.cpu().numpy()) < 1e-5   # atomics: order differs, values agree
 
 
+def test_scorer_is_reused_until_the_map_changes(config1, gpu):
+    """compute_Hessian is called once per path step (tester 1684-1705) on an unchanged map: the packed inputs and the
+    workspace are built once; any in-place update or replacement of a parameter tensor rebuilds them."""
+    import models.gaussian_slam as mgs
+    c = config1
+    slam = mgs.GaussianSLAM(params={k: v.clone() for k, v in c["params"].items()}, intrinsics=c["K"], width=c["W"], height=c["H"], device=gpu)
+    for w in c["kf_w2c"][:2]:
+        slam.add_keyframe(w)
+    a = slam._scorer()
+    h0 = slam.compute_Hessian(c["w2c"][0], return_points=True)
+    slam.pose_eval([p.to(gpu) for p in c["c2w"][:2]])
+    assert slam._scorer() is a
+    slam.params["logit_opacities"].mul_(0.5)                       # what an optimiser step does
+    b = slam._scorer()
+    assert b is not a
+    h1 = slam.compute_Hessian(c["w2c"][0], return_points=True)
+    assert not torch.equal(h0, h1)
+    slam.params["means3D"] = slam.params["means3D"].clone()        # what densification / pruning does
+    assert slam._scorer() is not b
+
+
 def test_per_view_weights_path_eval(config1, gpu):
     """H_inv_view_stride != 0: each view has its own weights (the planner's path evaluation, tester 1688-1705)."""
     c = config1

@@ -1,31 +1,46 @@
 #!/usr/bin/env python3
-"""Fold rocprofv3 --pmc counter_collection CSVs (one pass per counter set) into profiles/pmc_k_fisher_tile_v2.json.
-usage: tools/pmc_summary.py <tag> <csv> [<csv> ...]      (bench defaults: 500k Gaussians, 64 views, 256^2, C=4)"""
-import csv, collections, json, os, sys
+"""Fold the rocprofv3 --pmc passes of tools/pmc_collect.sh (one counter_collection.csv per counter group, merged back under
+gpurun_out/pmc_<tag>_<i>/) into profiles/pmc_k_fisher_tile_v3.json and copy the per-group folds to profiles/<tag>_pmc_<i>.txt.
+The record is stamped with the commit and the hash of the kernel sources it belongs to; bench.py ignores a record whose
+hash differs from the sources it runs.
+usage: tools/pmc_summary.py <tag> [contributing_pairs_per_launch walk_iterations_per_launch]   (bench defaults: 500k Gaussians, 64 views, 256^2, C=4)"""
+import collections, csv, glob, json, os, shutil, subprocess, sys
 
-tag, files = sys.argv[1], sys.argv[2:]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fisher-nerf-customized_amd"))
+from fisher_rast import _lib   # noqa: E402
+
+tag = sys.argv[1]
+KERNEL = "k_fisher_tile_v3"
 acc = collections.defaultdict(list)
+files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*", "*counter_collection.csv")))
+assert files, "no counter_collection.csv under gpurun_out/pmc_%s_*" % tag
 for f in files:
     for r in csv.DictReader(open(f)):
-        if "k_fisher_tile_v2<4, true, false>" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-m = {k: sum(v) / len(v) for k, v in acc.items()}
-out = {"kernel": "k_fisher_tile_v2<4,true,false>", "gaussians": 500000, "views": 64, "size": 256, "columns": 4, "round": tag}
+m = {k: sum(v[-3:]) / len(v[-3:]) for k, v in acc.items()}       # the last launches are the steady-state scorer launches
+out = {"kernel": KERNEL, "gaussians": 500000, "views": 64, "size": 256, "columns": 4, "round": tag,
+       "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip(),
+       "source_hash": _lib.source_hash(),
+       "command": "rocprofv3 --pmc <group> -d gpurun_out/pmc_<tag>_<i> -o pmc --output-format csv -- python3 tools/pmc_target.py 4   "
+                  "(tools/pmc_collect.sh: one pass per counter group, no trace options beside --pmc)"}
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     out["FETCH_SIZE_KiB"] = m["FETCH_SIZE"]; out["WRITE_SIZE_KiB"] = m["WRITE_SIZE"]
     out["hbm_bytes_per_launch"] = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
-    out["note"] = ("separate --pmc passes (profiles/%s_pmc_*.csv); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM "
-                   "section (FETCH_SIZE halves wide streaming reads on gfx950; this kernel's 8-32 B gathers are not a calibrated access shape)" % tag)
-for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
-          "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"):
-    if k in m: out[k] = m[k]
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# loop statistics of the same launch (tools/loopstats.py with a -DFR_LOOPSTATS build) are kept across refreshes
-try:
-    old = json.load(open(os.path.join(root, "profiles", "pmc_k_fisher_tile_v2.json")))
-    for k in ("contributing_pairs_per_launch", "pass1_iterations_per_launch", "walk_steps_per_launch", "loop_stats_note"):
-        if k in old: out[k] = old[k]
-except Exception:
-    pass
-json.dump(out, open(os.path.join(root, "profiles", "pmc_k_fisher_tile_v2.json"), "w"), indent=1)
+    out["note"] = ("bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md, HBM section (FETCH_SIZE halves wide streaming "
+                   "reads on gfx950; this kernel's 16-64 B gathers are not a calibrated access shape, so 2x is an upper bound)")
+for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+          "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+          "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "TCC_HIT_sum", "TCC_MISS_sum", "GRBM_GUI_ACTIVE"):
+    if k in m:
+        out[k] = m[k]
+if len(sys.argv) > 3:
+    out["contributing_pairs_per_launch"] = int(float(sys.argv[2]))
+    out["walk_iterations_per_launch"] = int(float(sys.argv[3]))
+    out["loop_stats_note"] = ("(pixel, splat) pairs that pass every test of forward.cu:338-363 and wave-level walk iterations of one "
+                              "64-view launch, counted by a -DFR_LOOPSTATS build (tools/loopstats.py, FR_DEBUG_MODE 5 and 4)")
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v3.json"), "w"), indent=1)
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_*.txt"))):
+    shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
 print(json.dumps(out, indent=1))

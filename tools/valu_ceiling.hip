@@ -10,6 +10,29 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ILP independent chains of v_pk_fma_f32 (two fp32 FMAs per lane per instruction) per lane
+template <int ILP>
+__global__ __launch_bounds__(256) void k_stream_pk(float* out, int iters, float c1, float c2)
+{
+	v2f a[ILP];
+#pragma unroll
+	for (int k = 0; k < ILP; k++) a[k] = v2f{ (float)(threadIdx.x + k) * 1e-3f, (float)(threadIdx.x + 2 * k) * 1e-3f };
+	const v2f m = { c1, c1 * 0.999f }, b = { c2, c2 * 2.f };
+	for (int i = 0; i < iters; i++)
+	{
+#pragma unroll
+		for (int r = 0; r < 64; r++)
+#pragma unroll
+			for (int k = 0; k < ILP; k++) a[k] = __builtin_elementwise_fma(a[k], m, b);
+	}
+	float s = 0.f;
+#pragma unroll
+	for (int k = 0; k < ILP; k++) s += a[k].x + a[k].y;
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // ILP independent v_fma_f32 chains per lane; 64 FMAs per chain per outer iteration.
 template <int ILP, int KIND>
 __global__ __launch_bounds__(256) void k_stream(float* out, int iters, float c1, float c2)
@@ -62,14 +85,50 @@ static void run(const char* name, int waves_per_simd, float* d_out, int insts_pe
 	       name, waves_per_simd, ILP, best, per_simd_per_ns, 2.4 / per_simd_per_ns, per_simd_per_ns * 1e9 * 1024.0);
 }
 
-int main()
+template <int ILP>
+static void run_pk(const char* name, int waves_per_simd, float* d_out)
+{
+	const int iters = 2000 / ILP > 0 ? 2000 / ILP : 1;
+	dim3 grid(256 * waves_per_simd), block(256);
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	hipLaunchKernelGGL((k_stream_pk<ILP>), grid, block, 0, 0, d_out, iters, 1.0001f, 1e-7f);
+	CHECK(hipDeviceSynchronize());
+	float best = 1e30f;
+	for (int rep = 0; rep < 5; rep++)
+	{
+		CHECK(hipEventRecord(e0, 0));
+		hipLaunchKernelGGL((k_stream_pk<ILP>), grid, block, 0, 0, d_out, iters, 1.0001f, 1e-7f);
+		CHECK(hipEventRecord(e1, 0));
+		CHECK(hipEventSynchronize(e1));
+		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		if (ms < best) best = ms;
+	}
+	const double wave_insts = (double)grid.x * 4.0 * iters * 64.0 * ILP;
+	const double per_simd_per_ns = wave_insts / 1024.0 / (best * 1e6);
+	printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"ilp\": %d, \"ms\": %.4f, \"wave_insts_per_ns_per_simd\": %.4f, "
+	       "\"cycles_per_inst_at_2.4GHz\": %.3f, \"chip_wave_insts_per_s\": %.4e}\n",
+	       name, waves_per_simd, ILP, best, per_simd_per_ns, 2.4 / per_simd_per_ns, per_simd_per_ns * 1e9 * 1024.0);
+}
+
+int main(int argc, char** argv)
 {
 	float* d_out;
 	CHECK(hipMalloc(&d_out, (size_t)256 * 8 * 256 * sizeof(float)));
+	if (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 'q')
+	{
+		// --quick (bench.py): the ceiling (independent FMAs) and the floor (one dependent chain) at the scorer's occupancy
+		run<8, 0>("v_fma_f32", 5, d_out, 1);
+		run<1, 0>("v_fma_f32 dependent chain", 5, d_out, 1);
+		CHECK(hipFree(d_out));
+		return 0;
+	}
 	const int wl[] = { 1, 2, 4, 5, 8 };
 	for (int w : wl) run<1, 0>("v_fma_f32 dependent chain", w, d_out, 1);
 	for (int w : wl) run<4, 0>("v_fma_f32", w, d_out, 1);
 	for (int w : wl) run<8, 0>("v_fma_f32", w, d_out, 1);
+	for (int w : wl) run_pk<1>("v_pk_fma_f32 dependent chain", w, d_out);
+	for (int w : wl) run_pk<4>("v_pk_fma_f32", w, d_out);
 	for (int w : wl) run<4, 1>("v_exp_f32+v_mul_f32", w, d_out, 2);
 	for (int w : wl) run<4, 2>("ds_bpermute_b32+v_add_f32", w, d_out, 2);
 	CHECK(hipFree(d_out));
