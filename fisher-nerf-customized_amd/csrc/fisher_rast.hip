@@ -48,6 +48,7 @@
 #include <vector>
 #include <utility>
 static thread_local char g_err[512] = "";
+static int fr_debug_mode();
 // measurement only: HIP events recorded around the dominant kernel on the stream it is launched on
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 
 // (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
 struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; };
-template <int C>
+template <int C, bool REWRITE>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c);
@@ -463,7 +464,7 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 // The arithmetic per pair is fr_preprocess_one's, so radii / rects / depths are bit-identical to k_preprocess.
 //   phase C  (RC != 0: score-only mode) the workgroup walks the compact lists it has just written and turns every visible
 //            (view, Gaussian) into the scorer's 96-byte record (fr_fisher_record_one) while the splat records are still in L2.
-template <int RC>
+template <int RC, bool PHASE_C>
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrRecordArgs ra)
 {
 	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12]
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	float* s_wm = (float*)(pairs + FR_THREADS * VC);
 	__shared__ uint32_t s_np;
 	__shared__ uint32_t s_n[16];
+	__shared__ uint32_t s_ref[16];               // tile instances by the reference's rule (radius rectangle), per view
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int v0 = blockIdx.y * VC;
 	const int nv = min(VC, p.V - v0);
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	for (int t = tid; t < nv * p.T; t += FR_THREADS) hist[t] = 0;
 	const bool has_w2c = p.w2c != nullptr;
 	if (has_w2c) for (int t = tid; t < nv * 12; t += FR_THREADS) s_wm[t] = p.w2c[16 * (size_t)(v0 + t / 12) + (t % 12)];
-	if (tid < 16) s_n[tid] = 0;
+	if (tid < 16) { s_n[tid] = 0; s_ref[tid] = 0; }
 	if (tid == 0) s_np = 0;
 	float vm[16], pm[16];
 #pragma unroll
@@ -536,17 +538,48 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 			if (s.radius > 0)
 			{
 				const float o = p.opac[i];
+				const uint32_t ext = fr_alpha_extent(s.conx, s.cony, s.conz, o);
 				float4* dst = (float4*)(p.splat + (size_t)v * p.P + i);
-				dst[0] = make_float4(s.px, s.py, s.conx, s.cony);
-				dst[1] = make_float4(s.conz, o, s.depth, __uint_as_float(fr_alpha_extent(s.conx, s.cony, s.conz, o)));
+				if constexpr (RC != 0)
+				{
+					// score-only mode: the scorer's {recA, recB} form straight away (see k_fisher_tile_v3)
+					const float cg = p.colors[3 * (size_t)i] + p.colors[3 * (size_t)i + 1] + p.colors[3 * (size_t)i + 2];
+					dst[0] = make_float4(s.px, s.py, __uint_as_float(ext), __builtin_amdgcn_logf(o));
+					dst[1] = make_float4(-0.5f * s.conx, -s.cony, -0.5f * s.conz, cg);
+				}
+				else
+				{
+					dst[0] = make_float4(s.px, s.py, s.conx, s.cony);
+					dst[1] = make_float4(s.conz, o, s.depth, __uint_as_float(ext));
+				}
+				// The reference lists the splat in every tile of its radius rectangle (rasterizer_impl.cu:70-111).  The scorer
+				// only ever uses a list entry where alpha can reach 1/255, so the rectangle is cut down to the tiles that the
+				// conservative alpha footprint (ext: half extents, rounded up) touches -- 16 % fewer keys to scatter, sort and
+				// stream on the benchmark scene; the reference's count is still what out_num_rendered reports.
+				uint32_t rx0 = s.rect.x0, rx1 = s.rect.x1, ry0 = s.rect.y0, ry1 = s.rect.y1;
+				atomicAdd(&s_ref[vv], (rx1 - rx0) * (ry1 - ry0));
+				{
+					const float hx = __half2float(__ushort_as_half((unsigned short)(ext & 0xffffu)));
+					const float hy = __half2float(__ushort_as_half((unsigned short)(ext >> 16)));
+					if (hx < 0.f) { rx1 = rx0; ry1 = ry0; }                  // opacity <= 1/255: contributes nowhere
+					else if (hx < 1e30f)
+					{
+						// pixel centres sit on integer coordinates: pixel x is inside when |x - px| <= hx
+						const float inv = 1.0f / (float)FR_BLOCK_X;
+						const int tx0 = (int)floorf((s.px - hx) * inv), tx1 = (int)floorf((s.px + hx) * inv) + 1;
+						const int ty0 = (int)floorf((s.py - hy) * inv), ty1 = (int)floorf((s.py + hy) * inv) + 1;
+						rx0 = (uint32_t)max((int)rx0, tx0); rx1 = (uint32_t)max((int)rx0, min((int)rx1, tx1));
+						ry0 = (uint32_t)max((int)ry0, ty0); ry1 = (uint32_t)max((int)ry0, min((int)ry1, ty1));
+					}
+				}
 				uint32_t* h = hist + (size_t)vv * p.T;
-				for (uint32_t y = s.rect.y0; y < s.rect.y1; y++)
-					for (uint32_t x = s.rect.x0; x < s.rect.x1; x++)
+				for (uint32_t y = ry0; y < ry1; y++)
+					for (uint32_t x = rx0; x < rx1; x++)
 						atomicAdd(&h[y * p.gx + x], 1u);
 				const uint32_t slot = atomicAdd(&s_n[vv], 1u);
 				FrVisEntry en;
 				en.idx = (uint32_t)i; en.depth_bits = fr_as_u32(s.depth);
-				en.xy0 = s.rect.x0 | (s.rect.y0 << 16); en.xy1 = s.rect.x1 | (s.rect.y1 << 16);
+				en.xy0 = rx0 | (ry0 << 16); en.xy1 = rx1 | (ry1 << 16);
 				*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + slot) = *(const uint4*)&en;
 			}
 		}
@@ -571,8 +604,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 		const int v = v0 + tid;
 		p.vis_n[(size_t)v * nblk + blockIdx.x] = s_n[tid];
 		if (p.vis_count && s_n[tid]) atomicAdd(&p.vis_count[v], (int)s_n[tid]);
+		if (p.num_rendered && s_ref[tid]) atomicAdd(&p.num_rendered[v], (int)s_ref[tid]);
 	}
-	if constexpr (RC != 0)
+	if constexpr (RC != 0 && PHASE_C)
 	{
 		// ---- phase C: the entries and splat records were written by this workgroup (same CU, same L1): visible after a barrier
 		__syncthreads();
@@ -585,7 +619,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 #pragma unroll
 			for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * vv + k] : 0.f;
 			for (uint32_t e = tid; e < n; e += FR_THREADS)
-				fr_fisher_record_one<RC>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
+				fr_fisher_record_one<RC, false>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
 		}
 	}
 }
@@ -1847,7 +1881,9 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 //     recA {x, y, ext, log2(opacity)}   recB {-conic.x/2, -conic.y, -conic.z/2, cg}    (in place of the FrSplat record)
 //     recQ {Q'[15], k3}                                                                 (64 B, [V][P])
 // ---------------------------------------------------------------------------------------------------------
-template <int C>
+// REWRITE: the (view, Gaussian) record still holds the rasteriser's FrSplat and is turned into {recA, recB} here (stand-alone
+// k_fisher_records); otherwise the front end has already written {recA, recB} and only recQ is produced.
+template <int C, bool REWRITE>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c)
@@ -1855,7 +1891,10 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	constexpr int PS = FrPackSize<C>::value;
 	constexpr bool SR = C >= 11;
 	float4* sp = (float4*)(p.splat + (size_t)v * p.P + id);
-	const float4 a0 = sp[0], a1 = sp[1];                 // {x, y, cx, cy} {cz, o, depth, ext}
+	float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;          // {x, y, cx, cy} {cz, o, depth, ext}
+	float opacity;
+	if constexpr (REWRITE) { a0 = sp[0]; a1 = sp[1]; opacity = a1.y; }
+	else opacity = p.opac[id];
 	float gsv[PS];
 	const float4* pk = (const float4*)(packed + (size_t)id * PS);
 #pragma unroll
@@ -1921,10 +1960,13 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 			}
 			qf[q++] = (i == j) ? acc : 2.0f * acc;
 		}
-	const float inv_o = __builtin_amdgcn_rcpf(a1.y);
+	const float inv_o = __builtin_amdgcn_rcpf(opacity);
 	qf[15] = inv_o * inv_o * hv[3];                      // dL_dopacity = G dL_dalpha = w / opacity, weighted by H_inv[3]
-	sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
-	sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
+	if constexpr (REWRITE)
+	{
+		sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
+		sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
+	}
 	float4* dq = recq + ((size_t)v * p.P + id) * 4;
 #pragma unroll
 	for (int k = 0; k < 4; k++) dq[k] = make_float4(qf[4 * k], qf[4 * k + 1], qf[4 * k + 2], qf[4 * k + 3]);
@@ -1950,7 +1992,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRec
 		const uint32_t n = p.vis_n[(size_t)v * nblk + blockIdx.x];
 		const FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * (size_t)(FR_THREADS * p.G);
 		for (uint32_t e = tid; e < n; e += FR_THREADS)
-			fr_fisher_record_one<C>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
+			fr_fisher_record_one<C, false>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);   // {recA, recB} came from k_preprocess_views
 	}
 	else
 	{
@@ -1958,7 +2000,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRec
 		{
 			const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
 			if (i < p.P && p.radii[(size_t)v * p.P + i] > 0)
-				fr_fisher_record_one<C>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
+				fr_fisher_record_one<C, true>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
 		}
 	}
 }
@@ -1966,6 +2008,57 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRec
 #define FR_ENT_F4 7                   // float4 per parked candidate record: 6 used + 1 pad -- a 28-dword stride spreads sixteen consecutive
                                      // candidates over all 64 LDS banks for ds_read_b128 (a 24-dword stride repeats after eight)
 typedef float fr_v4f __attribute__((ext_vector_type(4)));
+// One candidate's parked record as the walk reads it back (six ds_read_b128).
+struct FrWalkRec { fr_v4f a, b4, q0, q1, q2, q3; };     // {x, y, ext, log2 o} {-cx/2, -cy, -cz/2, cg} {Q'[15], k3}
+// Everything about one (pixel, candidate) pair that does not depend on the pixel's running state.
+struct FrWalkGeom { bool ok; float a_un, alpha, om1, bi, cg, add; };
+
+__device__ __forceinline__ FrWalkGeom fr_walk_geom(const FrWalkRec& r, float pfx, float pfy)
+{
+#pragma clang fp contract(fast)
+	FrWalkGeom g;
+	const float dx = r.a.x - pfx, dy = r.a.y - pfy;
+	float power;
+	const float e = fr_scorer_exponent(r.b4.x, r.b4.y, r.b4.z, dx, dy, r.a.w, power);
+	// forward.cu:347-357 (power > 0 -> skip, alpha < 1/255 -> skip); NaN falls through as it does there
+	g.ok = !(power > 0.0f) && !(e < FR_E255);
+	g.a_un = __builtin_amdgcn_exp2f(e);                                    // opacity * G
+	g.alpha = fminf(0.99f, g.a_un);
+	g.om1 = 1.f - g.alpha;
+	g.bi = __builtin_amdgcn_rcpf(g.om1);
+	g.cg = r.b4.w;
+	const float u0 = r.b4.x * dx + (r.b4.x * dx + r.b4.y * dy);           // -(cx dx + cy dy)
+	const float u1 = 2.0f * (r.b4.z * dy) + r.b4.y * dx;                    // -(cz dy + cy dx)
+	const float u2 = dx * dx, u3 = dx * dy, u4 = dy * dy;
+	// u'^T Q u' over the upper triangle (off-diagonal entries pre-doubled by fr_fisher_record_one), row by row
+	const float t0 = r.q0.x * u0 + r.q0.y * u1 + r.q0.z * u2 + r.q0.w * u3 + r.q1.x * u4;
+	const float t1 = r.q1.y * u1 + r.q1.z * u2 + r.q1.w * u3 + r.q2.x * u4;
+	const float t2 = r.q2.y * u2 + r.q2.z * u3 + r.q2.w * u4;
+	const float t3 = r.q3.x * u3 + r.q3.y * u4;
+	const float t4 = r.q3.z * u4;
+	const float add = r.q3.w + u0 * t0 + u1 * t1 + u2 * t2 + u3 * t3 + u4 * t4;
+	g.add = (g.a_un * g.a_un) * add;                                       // S_i = (opacity G)^2 (u'^T Q u' + k3)
+	return g;
+}
+
+// The pixel's recurrences for one candidate (`live`: it passed the pair tests and the pixel is not finished).
+// Returns true when the candidate ENDS the pixel (forward.cu:358-363: test_T < 1e-4, nothing is added).
+__device__ __forceinline__ bool fr_walk_update(const FrWalkGeom& g, bool live, float& T, float& Cg, float& Xt, float& sA, float& sB, float& sD)
+{
+#pragma clang fp contract(fast)
+	const float test_T = T * g.om1;
+	const bool kill = live && (test_T < 0.0001f);
+	const bool con = live && !kill;
+	const float S = con ? g.add : 0.f;
+	Xt = (con && T == 1.0f) ? g.cg : Xt;                                   // centre: the first contributor's colour
+	Cg = con ? Cg + g.cg * (g.alpha * T) : Cg;
+	const float pc = (Cg - Xt) * g.bi + T * g.cg;                          // p_i - Xt b_i
+	T = con ? test_T : T;
+	const float Sp = S * pc, Sb = S * g.bi;
+	sA += Sp * pc; sB += Sp * g.bi; sD += Sb * g.bi;
+	return kill;
+}
+
 #define FR_QCAP 128                  // per-wave candidate queue (ring of Gaussian indices): at most 63 left over + 64 new
 // One workgroup per (tile, view); the four waves own the four 16x4 strips and never synchronise until the final sum.
 //  stream   a wave reads the tile's sorted keys 64 at a time (one per lane), gathers recA and keeps the splats whose
@@ -1976,9 +2069,12 @@ typedef float fr_v4f __attribute__((ext_vector_type(4)));
 //  walk     every pixel-lane walks its own set bits front to back: six ds_read_b128 of the candidate's record, the pair
 //           test, the transmittance / colour prefix recurrences and the three sums.  A finished pixel clears its masks;
 //           a wave whose 64 pixels are finished leaves.
+// BW x BH = the 64 pixels of a wave inside the 16 x 16 tile: 16 x 4 strips (used), or 8 x 8 blocks (5 % slower on MI355X).
+template <int BW, int BH>
 __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5)))
 void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
 {
+	static_assert(BW * BH == 64 && 16 % BW == 0, "a wave owns 64 pixels of the tile");
 	__shared__ uint32_t s_q[4][FR_QCAP];
 	__shared__ float4 s_ent[4][64][FR_ENT_F4];
 	__shared__ float s_red[4];
@@ -1988,7 +2084,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	uint32_t tile; int v;
 	fr_tile_of_block(p, tile, v);
 	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
-	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	constexpr int WPR = 16 / BW;                   // waves per tile row
+	const uint32_t bx0 = tx * FR_BLOCK_X + (uint32_t)(wave % WPR) * BW, by0 = ty * FR_BLOCK_Y + (uint32_t)(wave / WPR) * BH;
+	const uint32_t pxx = bx0 + (uint32_t)(lane % BW), pxy = by0 + (uint32_t)(lane / BW);
 	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
 	const float pfx = (float)pxx, pfy = (float)pxy;
 	const size_t vt = (size_t)v * p.T + tile;
@@ -2001,8 +2099,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	float4 (*ent)[FR_ENT_F4] = s_ent[wave];
 	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];   // LDS byte address
 
-	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
-	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+	const float strip_lo = (float)by0, strip_hi = strip_lo + (float)(BH - 1);      // the wave's rows
+	const float tile_x0 = (float)bx0, tile_x1 = tile_x0 + (float)(BW - 1);         // ... and columns
 	float T = 1.0f, Cg = 0.f, Xt = 0.f, sA = 0.f, sB = 0.f, sD = 0.f;
 	bool done = !inside;
 	uint32_t qh = 0, qn = 0;                       // ring head / fill, wave-uniform
@@ -2063,7 +2161,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 			const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
 			const float racx = __builtin_amdgcn_rcpf(acx);
 #pragma unroll
-			for (unsigned r = 0; r < 4; r++)
+			for (unsigned r = 0; r < (unsigned)BH; r++)
 			{
 				const float dy = ay - (strip_lo + (float)r);
 				float lo = ax - ahx, hi2 = ax + ahx;                  // box fallback (unknown / degenerate conic)
@@ -2078,12 +2176,12 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 					const float dlo = (-hb - sq) * racx, dhi = (-hb + sq) * racx;   // dx in [dlo, dhi]
 					lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;               // pixel x = mean.x - dx
 				}
-				const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, 15.f);
+				const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, (float)(BW - 1));
 				if (any_px && c0f <= c1f)
 				{
 					const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f;
 					const unsigned long long cols = (unsigned long long)(((2u << c1) - 1u) & ~((1u << c0) - 1u));
-					emask |= cols << (16 * r);
+					emask |= cols << (BW * r);
 				}
 			}
 		}
@@ -2092,65 +2190,33 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		if (done) mask = 0ull;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		// ---- walk: every pixel-lane walks its own candidates front to back
+		// ---- walk: every pixel-lane walks its own candidates front to back (the set bits of `mask`).  The candidate's 96-byte
+		// record comes back as six ds_read_b128 (hipcc splits plain float4 LDS loads into dword pairs here).
+		// The loop is bound by VALU issue: ~4 cycles per wave64 instruction in a dependent chain (tools/valu_ceiling.hip).
+		// Tried on MI355X without gain: two candidates per trip (instruction-level parallelism), prefetching the next record
+		// while the current one is evaluated, two pixels per lane with packed v_pk_*_f32 arithmetic (32 % slower: the
+		// per-chunk walk length is set by the busiest lane either way).
 		while (mask != 0ull)
 		{
 			const int j = __ffsll((long long)mask) - 1;
 			mask &= mask - 1ull;
-			// the candidate's 96-byte record: six ds_read_b128 (hipcc splits plain float4 loads into dword pairs here)
-			fr_v4f a, b4, q0, q1, q2, q3;
+			FrWalkRec r;
 			{
 				const uint32_t addr = ent_lds + (uint32_t)j * (FR_ENT_F4 * 16);
 				asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
 				             "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
 				             "s_waitcnt lgkmcnt(0)"
-				             : "=&v"(a), "=&v"(b4), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
+				             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2), "=&v"(r.q3) : "v"(addr) : "memory");
 			}
 #ifdef FR_LOOPSTATS
 			dbg_steps++; dbg_cs++;
 #endif
-			const float dx = a.x - pfx, dy = a.y - pfy;
-			float power;
-			const float e = fr_scorer_exponent(b4.x, b4.y, b4.z, dx, dy, a.w, power);
-			{
-#pragma clang fp contract(fast)
-				// forward.cu:347-357 (power > 0 -> skip, alpha < 1/255 -> skip); NaN falls through as it does there
-				const bool ok = !(power > 0.0f) && !(e < FR_E255);
-				const float a_un = __builtin_amdgcn_exp2f(e);                          // opacity * G
-				const float alpha = fminf(0.99f, a_un);
-				const float om1 = 1.f - alpha;
-				const float test_T = T * om1;
-				const bool kill = ok && (test_T < 0.0001f);                            // forward.cu:358-363: the pixel is finished
-				const bool con = ok && !kill;
+			const FrWalkGeom g = fr_walk_geom(r, pfx, pfy);
+			const bool kill = fr_walk_update(g, g.ok, T, Cg, Xt, sA, sB, sD);
 #ifdef FR_LOOPSTATS
-				dbg_hits += con ? 1 : 0;
+			dbg_hits += (g.ok && !kill) ? 1 : 0;
 #endif
-				if (kill) { mask = 0ull; done = true; }
-				const float bi = __builtin_amdgcn_rcpf(om1);
-				const float cg = b4.w;
-				float u[5];
-				u[0] = b4.x * dx + (b4.x * dx + b4.y * dy);                            // -(cx dx + cy dy)
-				u[1] = 2.0f * (b4.z * dy) + b4.y * dx;                                 // -(cz dy + cy dx)
-				u[2] = dx * dx; u[3] = dx * dy; u[4] = dy * dy;
-				const float qv[15] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z };
-				float add = q3.w;
-				int q = 0;
-#pragma unroll
-				for (int i = 0; i < 5; i++)
-				{
-					float ti = 0.f;
-#pragma unroll
-					for (int jj = i; jj < 5; jj++) ti += qv[q++] * u[jj];
-					add += u[i] * ti;
-				}
-				const float S = con ? (a_un * a_un) * add : 0.f;
-				Xt = (con && T == 1.0f) ? cg : Xt;                                     // centre: the first contributor's colour
-				Cg = con ? Cg + cg * (alpha * T) : Cg;
-				const float pc = (Cg - Xt) * bi + T * cg;                              // p_i - Xt b_i
-				T = con ? test_T : T;
-				const float Sp = S * pc, Sb = S * bi;
-				sA += Sp * pc; sB += Sp * bi; sD += Sb * bi;
-			}
+			if (kill) { mask = 0ull; done = true; }
 		}
 		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
 #ifdef FR_LOOPSTATS
@@ -2940,6 +3006,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		FrZeroer z;
 		z.add(p.tile_cnt, (size_t)p.V * p.T * 4); z.add(p.status, 16); z.add(p.big_list, 64);
 		if (p.vis_count) z.add(p.vis_count, (size_t)p.V * 4);
+		if (p.num_rendered && p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES) z.add(p.num_rendered, (size_t)p.V * 4);   // counted by k_preprocess_views
 		z.launch(s);
 	}
 	if (g->cov3D_precomp) p.cov3D = g->cov3D_precomp;
@@ -2969,9 +3036,12 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC) * 4;
 		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr };
-		if (!plan) hipLaunchKernelGGL((k_preprocess_views<0>), gridV, dim3(FR_THREADS), lds, s, p, ra);
-		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4>), gridV, dim3(FR_THREADS), lds, s, p, ra);
-		else hipLaunchKernelGGL((k_preprocess_views<11>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
+		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
+		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
+		if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		else hipLaunchKernelGGL((k_preprocess_views<11, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		if ((rc = fr_check_launch("k_preprocess_views"))) return rc;
 	}
 	else
@@ -2994,7 +3064,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		}
 	}
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
-	                   p.key_capacity, p.status, p.num_rendered, p.big_list);
+	                   p.key_capacity, p.status, multi ? (int*)nullptr : p.num_rendered, p.big_list);
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
 	if (multi) hipLaunchKernelGGL(k_scatter_vis, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	else hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
@@ -3002,7 +3072,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	// The three sort tiers touch disjoint tile segments.  The 1024-thread tier has few, long-running workgroups (one per
 	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
 	FrSideStream& side = fr_side_stream();
-	const bool forked = side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
+	const bool forked = fr_debug_mode() != 7 && side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;   // FR_DEBUG_MODE=7: every sort tier on the caller's stream (timing ablation)
 	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
 	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
@@ -3351,7 +3421,9 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
 		(void)hipEventRecord(ev0, s);
 	}
-	hipLaunchKernelGGL(k_fisher_tile_v3, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	// FR_DEBUG_MODE=8: 8 x 8 pixel blocks per wave instead of 16 x 4 strips (A/B runs; measured 5 % slower on MI355X)
+	if (f.debug_mode == 8) hipLaunchKernelGGL((k_fisher_tile_v3<8, 8>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	else hipLaunchKernelGGL((k_fisher_tile_v3<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);
