@@ -3539,6 +3539,102 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 }
 
 // =========================================================================================================
+// Densification / pruning statistics of the training step.  The reference spreads these over a dozen torch
+// ops per mapping iteration (gaussian.py:289-292; slam_external.py:196-200, 345-465); here each is one pass over the
+// Gaussians.  exp / sigmoid use fr_expf + IEEE division, the sequence the oracle restates, so the masks are reproducible
+// bit for bit.
+// =========================================================================================================
+// after a render + backward: seen = radius > 0; max_2D_radius = max(radius, max_2D_radius) where seen (gaussian.py:289-291);
+// means2D_gradient_accum += |means2D.grad.xy|, denom += 1 where seen (slam_external.py:196-200; skipped when grad is null)
+__global__ __launch_bounds__(FR_THREADS) void k_densify_stats(int P, const int* __restrict__ radii, const float* __restrict__ grad_means2D,
+                                                              float* __restrict__ max_radius, float* __restrict__ grad_accum,
+                                                              float* __restrict__ denom, uint8_t* __restrict__ seen)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= P) return;
+	const int r = radii[i];
+	const bool vis = r > 0;
+	if (seen) seen[i] = vis ? 1 : 0;
+	if (!vis) return;
+	if (max_radius) max_radius[i] = fmaxf((float)r, max_radius[i]);
+	if (grad_means2D)
+	{
+		const float gx = grad_means2D[3 * (size_t)i], gy = grad_means2D[3 * (size_t)i + 1];
+		grad_accum[i] += sqrtf(gx * gx + gy * gy);
+		denom[i] += 1.0f;
+	}
+}
+
+__device__ __forceinline__ float fr_max_scale(const float* __restrict__ log_scales, int scale_cols, int i)
+{
+	float m = fr_expf(log_scales[(size_t)i * scale_cols]);
+	for (int k = 1; k < scale_cols; k++) m = fmaxf(m, fr_expf(log_scales[(size_t)i * scale_cols + k]));
+	return m;
+}
+
+// slam_external.py:419-433: grads = accum / denom (NaN -> 0); to_clone = grads >= grad_thresh AND max scale <= clone_max_scale;
+// to_split = max scale > split_min_scale -- the reference applies no gradient test to the split (its padded_grad is unused)
+__global__ __launch_bounds__(FR_THREADS) void k_densify_masks(int P, const float* __restrict__ grad_accum, const float* __restrict__ denom,
+                                                              const float* __restrict__ log_scales, int scale_cols, float grad_thresh,
+                                                              float clone_max_scale, float split_min_scale,
+                                                              uint8_t* __restrict__ to_clone, uint8_t* __restrict__ to_split)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= P) return;
+	float g = grad_accum[i] / denom[i];
+	if (g != g) g = 0.0f;
+	const float ms = fr_max_scale(log_scales, scale_cols, i);
+	to_clone[i] = (g >= grad_thresh && ms <= clone_max_scale) ? 1 : 0;
+	to_split[i] = (ms > split_min_scale) ? 1 : 0;
+}
+
+// slam_external.py:354, 394-396, 452-457: to_remove = sigmoid(logit_opacity) < opacity_thresh OR (big_thresh >= 0 AND max scale > big_thresh)
+__global__ __launch_bounds__(FR_THREADS) void k_prune_mask(int P, const float* __restrict__ logit_opacities, const float* __restrict__ log_scales,
+                                                           int scale_cols, float opacity_thresh, float big_thresh, uint8_t* __restrict__ to_remove)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= P) return;
+	const float op = 1.0f / (1.0f + fr_expf(-logit_opacities[i]));
+	bool rm = op < opacity_thresh;
+	if (big_thresh >= 0.0f) rm = rm || (fr_max_scale(log_scales, scale_cols, i) > big_thresh);
+	to_remove[i] = rm ? 1 : 0;
+}
+
+extern "C" int fr_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float* max_2D_radius,
+                                float* means2D_gradient_accum, float* denom, uint8_t* seen, fr_stream_t stream)
+{
+	if (P < 0) return fr_fail(FR_EINVAL, "fr_densify_stats: P < 0");
+	if (P == 0) return FR_OK;
+	if (!radii || (grad_means2D && (!means2D_gradient_accum || !denom))) return fr_fail(FR_EINVAL, "fr_densify_stats: null pointer");
+	hipLaunchKernelGGL(k_densify_stats, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, (hipStream_t)stream,
+	                   P, radii, grad_means2D, max_2D_radius, means2D_gradient_accum, denom, seen);
+	return fr_check_launch("k_densify_stats");
+}
+
+extern "C" int fr_densify_masks(int32_t P, const float* means2D_gradient_accum, const float* denom, const float* log_scales,
+                                int32_t scale_cols, float grad_thresh, float clone_max_scale, float split_min_scale,
+                                uint8_t* to_clone, uint8_t* to_split, fr_stream_t stream)
+{
+	if (P < 0 || (scale_cols != 1 && scale_cols != 3)) return fr_fail(FR_EINVAL, "fr_densify_masks: bad P / scale_cols");
+	if (P == 0) return FR_OK;
+	if (!means2D_gradient_accum || !denom || !log_scales || !to_clone || !to_split) return fr_fail(FR_EINVAL, "fr_densify_masks: null pointer");
+	hipLaunchKernelGGL(k_densify_masks, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, (hipStream_t)stream,
+	                   P, means2D_gradient_accum, denom, log_scales, scale_cols, grad_thresh, clone_max_scale, split_min_scale, to_clone, to_split);
+	return fr_check_launch("k_densify_masks");
+}
+
+extern "C" int fr_prune_mask(int32_t P, const float* logit_opacities, const float* log_scales, int32_t scale_cols,
+                             float opacity_thresh, float big_thresh, uint8_t* to_remove, fr_stream_t stream)
+{
+	if (P < 0 || (scale_cols != 1 && scale_cols != 3)) return fr_fail(FR_EINVAL, "fr_prune_mask: bad P / scale_cols");
+	if (P == 0) return FR_OK;
+	if (!logit_opacities || !to_remove || (big_thresh >= 0.0f && !log_scales)) return fr_fail(FR_EINVAL, "fr_prune_mask: null pointer");
+	hipLaunchKernelGGL(k_prune_mask, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, (hipStream_t)stream,
+	                   P, logit_opacities, log_scales, scale_cols, opacity_thresh, big_thresh, to_remove);
+	return fr_check_launch("k_prune_mask");
+}
+
+// =========================================================================================================
 // simple-knn: distCUDA2.  Upstream (gitlab.inria.fr/bkerbl/simple-knn, not vendored in the reference) orders the
 // points along a Morton curve, boxes them 1024 at a time and prunes boxes by their distance to the query; the
 // result is the EXACT mean squared distance to the 3 nearest other points, so any exact search reproduces it.

@@ -81,7 +81,7 @@ class OccCfg(ctypes.Structure):
 EXPORTS = (
     "fr_version", "fr_last_error", "fr_build_id", "fr_init", "fr_fisher_workspace_layout", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
     "fr_forward", "fr_backward", "fr_forward_pair", "fr_forward_features", "fr_backward_pair", "fr_fisher_workspace_bytes", "fr_fisher_views",
-    "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
+    "fr_densify_stats", "fr_densify_masks", "fr_prune_mask", "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
     "fr_occ_workspace_bytes", "fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of",
     "fr_occ_ring_candidates", "fr_occ_free_candidates",
 )
@@ -173,6 +173,13 @@ def load():
     lib.fr_fisher_views.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians),
                                     ctypes.POINTER(FisherCfg), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64,
                                     ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_densify_stats.restype = ctypes.c_int
+    lib.fr_densify_stats.argtypes = [ctypes.c_int32, ctypes.c_void_p, _f32p, _f32p, _f32p, _f32p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_densify_masks.restype = ctypes.c_int
+    lib.fr_densify_masks.argtypes = [ctypes.c_int32, _f32p, _f32p, _f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fr_prune_mask.restype = ctypes.c_int
+    lib.fr_prune_mask.argtypes = [ctypes.c_int32, _f32p, _f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
     lib.fr_knn_workspace_bytes.restype = ctypes.c_size_t
     lib.fr_knn_workspace_bytes.argtypes = [ctypes.c_int32]
     lib.fr_knn_dist2.restype = ctypes.c_int

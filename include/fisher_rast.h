@@ -26,6 +26,8 @@
  *                           models/SLAM/gaussian.py:1338-1375, 1503-1570 and
  *                           models/SLAM/gaussian_object.py:1541-1551, 1591-1617, 1940-2045
  *                           (V x [forward + backward(power=2) + cat + sum]) as one batched call
+ *   fr_densify_stats / fr_densify_masks / fr_prune_mask <- the statistics of get_loss / densify / prune_gaussians
+ *                           models/SLAM/gaussian.py:289-291, models/SLAM/utils/slam_external.py:196-200, 345-465
  *   fr_knn_dist2         <- simple_knn._C.distCUDA2 (thirdparty/simple-knn, un-vendored submodule)
  *
  * The pybind module `_C` of the reference (RAST/ext.cpp:14-18) is re-created in Python on top of
@@ -190,6 +192,28 @@ int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32_t n_views,
 int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, const fr_fisher_cfg* cfg_f,
                     void* workspace, size_t workspace_bytes, int64_t max_rendered,
                     int32_t* status, fr_stream_t stream);
+
+/* ---- densification / pruning statistics of the training step ---------------------------
+ * One pass over the Gaussians each, in place of the torch-op chains of models/SLAM/gaussian.py:289-291 and
+ * models/SLAM/utils/slam_external.py:196-200, 345-465.  All arrays are device float32 [P] unless noted. */
+
+/* After a render (+ backward): seen[i] = radii[i] > 0 (uint8, may be null); where seen: max_2D_radius = max(radius, max_2D_radius)
+ * (may be null) and -- when grad_means2D ([P,3], the colour render's means2D.grad) is given -- means2D_gradient_accum += |grad.xy|,
+ * denom += 1 (accumulate_mean2d_gradient). */
+int fr_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float* max_2D_radius,
+                     float* means2D_gradient_accum, float* denom, uint8_t* seen, fr_stream_t stream);
+
+/* densify(): grads = accum / denom with NaN -> 0; to_clone = grads >= grad_thresh AND max_k exp(log_scales) <= clone_max_scale;
+ * to_split = max_k exp(log_scales) > split_min_scale (the reference applies no gradient test to the split).
+ * log_scales: [P, scale_cols], scale_cols 1 (isotropic) or 3.  Masks: uint8 [P]. */
+int fr_densify_masks(int32_t P, const float* means2D_gradient_accum, const float* denom, const float* log_scales,
+                     int32_t scale_cols, float grad_thresh, float clone_max_scale, float split_min_scale,
+                     uint8_t* to_clone, uint8_t* to_split, fr_stream_t stream);
+
+/* prune_gaussians() / the removal pass of densify(): to_remove = sigmoid(logit_opacities) < opacity_thresh
+ * OR (big_thresh >= 0 AND max_k exp(log_scales) > big_thresh).  uint8 [P]. */
+int fr_prune_mask(int32_t P, const float* logit_opacities, const float* log_scales, int32_t scale_cols,
+                  float opacity_thresh, float big_thresh, uint8_t* to_remove, fr_stream_t stream);
 
 /* ---- simple-knn ---------------------------------------------------------------------------------- */
 
