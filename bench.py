@@ -434,7 +434,9 @@ def main():
 
     if rank == 0:
         views_per_s = V_total * a.steps / dt
-        R = float(num_rendered.sum())          # tile instances of this rank's V views
+        # tile instances one launch processes: the keys actually listed (status[0]); `num_rendered` keeps the reference's count
+        # (radius rectangles), the front end lists a splat only in the tiles its alpha footprint reaches
+        R = float(int(last["status"].cpu()[0]))
         T = ((W + 15) // 16) * ((H + 15) // 16)
         # algorithmic bytes of ONE k_fisher_tile_v3 launch: per tile instance the sorted key (8 B), the
         # 32-byte {recA, recB} record and the 64-byte recQ record, each moved once; plus one partial score per (view, tile)
@@ -465,7 +467,8 @@ def main():
             "config": {"workload": f"{P} Gaussians (room_shell seed {seed}), {V_total} candidate {W}x{H} views per step"
                                    f" ({V} on this GPU), Fisher columns {C}, H_inv from 16 keyframes; BASELINE.json configs[{1 if world == 1 else 2}]",
                        "gaussians": P, "views_per_gpu": V, "views_total": V_total, "image": [H, W], "columns": C,
-                       "tile_instances_per_view": float(num_rendered.mean()), "visible_per_view": float(vis_count.mean()),
+                       "tile_instances_per_view": float(num_rendered.mean()), "listed_tile_instances_per_view": R / max(V, 1),
+                       "visible_per_view": float(vis_count.mean()),
                        "parallelism": f"views sharded over {world} GPU(s), scores all-gathered" if world > 1 else "1 GPU"},
             "fisher_scores_per_s": views_per_s * P * C,
             "build": {"build_id": lib.fr_build_id().decode(), "so_path": os.path.relpath(_lib.SO_PATH, ROOT)},
