@@ -2106,6 +2106,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	uint32_t qh = 0, qn = 0;                       // ring head / fill, wave-uniform
 #ifdef FR_LOOPSTATS
 	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0, dbg_cs = 0;
+	long long dbg_t0 = 0, dbg_ts = 0, dbg_tc = 0, dbg_tw = 0;     // s_memtime sums: stream / chunk set-up / walk
 #endif
 
 	// software pipeline of the key stream: id1 / r1 = indices and recA of the chunk at `base`, id2 = indices of the next one
@@ -2118,6 +2119,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	while (!all_done)
 	{
 		// ---- stream: fill the queue up to one chunk
+#ifdef FR_LOOPSTATS
+		dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
 		while (qn < 64u && base < n)
 		{
 			const uint32_t idc = id1; const float4 rc = r1;
@@ -2134,6 +2138,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 			qn += (uint32_t)__popcll(om);
 			base += 64;
 		}
+#ifdef FR_LOOPSTATS
+		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_ts += t - dbg_t0; dbg_t0 = t; }
+#endif
 		if (qn == 0) break;
 		// ---- chunk: up to 64 candidates, one per lane
 		const uint32_t m = qn < 64u ? qn : 64u;
@@ -2190,12 +2197,14 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		if (done) mask = 0ull;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+#ifdef FR_LOOPSTATS
+		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; dbg_t0 = t; }
+#endif
 		// ---- walk: every pixel-lane walks its own candidates front to back (the set bits of `mask`).  The candidate's 96-byte
 		// record comes back as six ds_read_b128 (hipcc splits plain float4 LDS loads into dword pairs here).
-		// The loop is bound by VALU issue: ~4 cycles per wave64 instruction in a dependent chain (tools/valu_ceiling.hip).
-		// Tried on MI355X without gain: two candidates per trip (instruction-level parallelism), prefetching the next record
-		// while the current one is evaluated, two pixels per lane with packed v_pk_*_f32 arithmetic (32 % slower: the
-		// per-chunk walk length is set by the busiest lane either way).
+		// The number of steps (set by the busiest lane of the chunk) times a per-step latency is what this loop costs; DESIGN.md
+		// section 4 lists what was tried on it without gain (two candidates per trip, prefetching the next record, two pixels per
+		// lane with packed arithmetic, per-row polynomials, arithmetic predicates in a wave-uniform loop, 4 / 5 / 6 waves per SIMD).
 		while (mask != 0ull)
 		{
 			const int j = __ffsll((long long)mask) - 1;
@@ -2220,6 +2229,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		}
 		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
 #ifdef FR_LOOPSTATS
+		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tw += t - dbg_t0; dbg_t0 = t; }
 		dbg_wsteps += wave_max_i(dbg_cs); dbg_cs = 0;
 #endif
 	}
@@ -2232,6 +2242,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	if (f.debug_mode >= 2)
 	{
 		// 2: candidates, 3: chunks, 4: wave-level walk iterations, 5: contributing pairs, 6: lane-level walk steps, 7: steps of the busiest lane
+		// 10 / 11 / 12: the wave's s_memtime ticks (/ 64) in the key stream / the chunk set-up / the walk
+		if (f.debug_mode >= 10) ws = (float)((f.debug_mode == 10 ? dbg_ts : f.debug_mode == 11 ? dbg_tc : dbg_tw) >> 6);
+		else
 		ws = f.debug_mode == 2 ? (float)dbg_cand : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_wsteps
 		   : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : f.debug_mode == 7 ? (float)wave_max_i(dbg_steps) : wave_sum((float)dbg_steps);
 	}

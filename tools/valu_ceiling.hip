@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void k_stream(float* out, int iters, float c1,
 	float a[ILP];
 #pragma unroll
 	for (int k = 0; k < ILP; k++) a[k] = (float)(threadIdx.x + k) * 1e-3f;
+	// per-lane multiplier / addend for KIND 3 (values the compiler cannot move to the scalar file)
+	const float vb = c1 + (float)(threadIdx.x & 7) * 1e-9f, vc = c2 * (float)(1 + (threadIdx.x & 3));
 	for (int i = 0; i < iters; i++)
 	{
 #pragma unroll
@@ -47,7 +49,8 @@ __global__ __launch_bounds__(256) void k_stream(float* out, int iters, float c1,
 #pragma unroll
 			for (int k = 0; k < ILP; k++)
 			{
-				if (KIND == 0) a[k] = __builtin_fmaf(a[k], c1, c2);                 // v_fma_f32
+				if (KIND == 0) a[k] = __builtin_fmaf(a[k], c1, c2);                 // v_fma_f32, one VGPR source (c1, c2 live in SGPRs)
+				else if (KIND == 3) a[k] = __builtin_fmaf(a[k], vb, vc);             // v_fma_f32, three VGPR sources
 				else if (KIND == 1) a[k] = __builtin_amdgcn_exp2f(a[k]) * c1;      // v_exp_f32 + v_mul_f32
 				else a[k] = __int_as_float(__builtin_amdgcn_ds_bpermute((threadIdx.x & 63) << 2, __float_as_int(a[k]))) + c2;   // ds_bpermute_b32 + v_add_f32
 			}
@@ -120,6 +123,7 @@ int main(int argc, char** argv)
 		// --quick (bench.py): the ceiling (independent FMAs) and the floor (one dependent chain) at the scorer's occupancy
 		run<8, 0>("v_fma_f32", 5, d_out, 1);
 		run<1, 0>("v_fma_f32 dependent chain", 5, d_out, 1);
+		run<8, 3>("v_fma_f32 with three VGPR sources", 5, d_out, 1);
 		CHECK(hipFree(d_out));
 		return 0;
 	}
@@ -127,6 +131,8 @@ int main(int argc, char** argv)
 	for (int w : wl) run<1, 0>("v_fma_f32 dependent chain", w, d_out, 1);
 	for (int w : wl) run<4, 0>("v_fma_f32", w, d_out, 1);
 	for (int w : wl) run<8, 0>("v_fma_f32", w, d_out, 1);
+	for (int w : wl) run<8, 3>("v_fma_f32 with three VGPR sources", w, d_out, 1);
+	for (int w : wl) run<1, 3>("v_fma_f32 with three VGPR sources, dependent chain", w, d_out, 1);
 	for (int w : wl) run_pk<1>("v_pk_fma_f32 dependent chain", w, d_out);
 	for (int w : wl) run_pk<4>("v_pk_fma_f32", w, d_out);
 	for (int w : wl) run<4, 1>("v_exp_f32+v_mul_f32", w, d_out, 2);
