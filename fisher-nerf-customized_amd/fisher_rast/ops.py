@@ -241,7 +241,7 @@ class FisherScorer:
     device status word when results are fetched (`fetch`), and the batch is re-run with a larger buffer.
     """
 
-    WORKSPACE_BUDGET = 8 << 30  # bytes of per-view workspace before views are processed in chunks
+    WORKSPACE_BUDGET = 32 << 30  # bytes of workspace (of the MI355X's 288 GB) before views are processed in chunks: ~580 views at 500k Gaussians
 
     def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
                  dL_dpix: float = 1e-3):
@@ -279,7 +279,11 @@ class FisherScorer:
 
     # -- helpers -------------------------------------------------------------------------------------
     def max_views_per_launch(self):
-        per_view = max(self.P, 1) * 36 + self.per_view_capacity * 8
+        """Views per fr_fisher_views call that keep the workspace within WORKSPACE_BUDGET (the per-view share is what the
+        library itself reports: records, visible lists, keys, per-tile arrays)."""
+        one = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 1, self.per_view_capacity, self.columns))
+        eight = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 8, 8 * self.per_view_capacity, self.columns))
+        per_view = max(1, (eight - one) // 7)
         return max(1, int(self.WORKSPACE_BUDGET // per_view))
 
     def _workspace(self, V, max_rendered, slot=0):
