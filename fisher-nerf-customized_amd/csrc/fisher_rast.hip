@@ -447,7 +447,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 
 // (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
 struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; };
-template <int C, bool REWRITE>
+template <int C, bool REWRITE, bool FORM_A = false>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c);
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 #pragma unroll
 			for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * vv + k] : 0.f;
 			for (uint32_t e = tid; e < n; e += FR_THREADS)
-				fr_fisher_record_one<RC, false>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
+				fr_fisher_record_one<(RC < 0 ? -RC : RC), false, (RC < 0)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
 		}
 	}
 }
@@ -1883,7 +1883,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 // ---------------------------------------------------------------------------------------------------------
 // REWRITE: the (view, Gaussian) record still holds the rasteriser's FrSplat and is turned into {recA, recB} here (stand-alone
 // k_fisher_records); otherwise the front end has already written {recA, recB} and only recQ is produced.
-template <int C, bool REWRITE>
+template <int C, bool REWRITE, bool FORM_A>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c)
@@ -1928,6 +1928,23 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 #pragma unroll
 			for (int c = 0; c < 3; c++) Cp[r][c] = -0.5f * Cm[r][c];
 		go = 19;
+	}
+	if constexpr (FORM_A)
+	{
+		// out_H mode (k_fisher_tile_v3h): the walk needs the three mean rows themselves, not their H_inv-weighted form
+		static_assert(!FORM_A || C == 4, "the A-form record holds the 3 x 5 mean Jacobian only");
+		const float inv_oa = __builtin_amdgcn_rcpf(opacity);
+		if constexpr (REWRITE)
+		{
+			sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
+			sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
+		}
+		float4* da = recq + ((size_t)v * p.P + id) * 4;
+		da[0] = make_float4(Ap[0][0], Ap[0][1], Ap[0][2], Ap[0][3]);
+		da[1] = make_float4(Ap[0][4], Ap[1][0], Ap[1][1], Ap[1][2]);
+		da[2] = make_float4(Ap[1][3], Ap[1][4], Ap[2][0], Ap[2][1]);
+		da[3] = make_float4(Ap[2][2], Ap[2][3], Ap[2][4], inv_oa * inv_oa);
+		return;
 	}
 	float hv[C];
 	if (hinv_stride != 0)
@@ -1974,10 +1991,10 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 
 // Stand-alone form of phase C of k_preprocess_views, for the single-view front end (images beyond FR_MAX_LDS_TILES tiles,
 // visibility from radii) -- or over the compact lists (LIST).  Needs the projection only, not the keys.
-template <int C, bool LIST>
+template <int C, bool LIST, bool FORM_A>
 __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRecordArgs ra)
 {
-	// (no overflow check: this kernel runs beside the scan that raises the flag)
+	if (p.status[1]) return;
 	const int tid = threadIdx.x;
 	const int v = blockIdx.y;
 	const uint32_t nblk = gridDim.x;
@@ -1992,7 +2009,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRec
 		const uint32_t n = p.vis_n[(size_t)v * nblk + blockIdx.x];
 		const FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * (size_t)(FR_THREADS * p.G);
 		for (uint32_t e = tid; e < n; e += FR_THREADS)
-			fr_fisher_record_one<C, false>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);   // {recA, recB} came from k_preprocess_views
+			fr_fisher_record_one<C, false, FORM_A>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);   // {recA, recB} came from k_preprocess_views
 	}
 	else
 	{
@@ -2000,7 +2017,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRec
 		{
 			const int i = (blockIdx.x * p.G + g) * FR_THREADS + tid;
 			if (i < p.P && p.radii[(size_t)v * p.P + i] > 0)
-				fr_fisher_record_one<C, true>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
+				fr_fisher_record_one<C, true, FORM_A>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, (uint32_t)i, vm, pm, wm, has_w2c);
 		}
 	}
 }
@@ -2254,6 +2271,319 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	if (lane == 0) s_red[wave] = ws;
 	__syncthreads();
 	if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out_H mode of the third generation (no H_inv, constant upstream gradient, 4 columns: compute_Hessian / H_train of the
+// scene map): the per-Gaussian diagonal itself is wanted, so the pixel's X = Cg_final + T_final sum(bg) has to be known
+// before a pair can be squared.  Two front-to-back passes of the same wave over the same list:
+//   pass 1   transmittance / colour prefix only (recA + recB, two ds_read_b128 per pair)            -> X per pixel
+//   pass 2   replays the recurrences (same arithmetic, hence the same contributor set), forms
+//            w = opacity G (T_i cg_i - (X - Cg_<=i) b_i) and the three mean rows A'_r . u' of the record (A-form of
+//            fr_fisher_record_one), squares and adds them into wave-private LDS accumulators [column][candidate];
+//   flush    per chunk, consecutive lanes on consecutive columns of one Gaussian (global float atomics into out_H).
+// Against k_fisher_tile_v2 this drops the per-chunk Jacobian chains (they are in the records), the contributor lists and
+// the back-to-front order.
+struct FrPairAlpha { bool ok; float dx, dy, a_un, alpha, om1; };
+__device__ __forceinline__ FrPairAlpha fr_pair_alpha(const fr_v4f& a, const fr_v4f& b4, float pfx, float pfy)
+{
+	FrPairAlpha g;
+	g.dx = a.x - pfx; g.dy = a.y - pfy;
+	float power;
+	const float e = fr_scorer_exponent(b4.x, b4.y, b4.z, g.dx, g.dy, a.w, power);
+	g.ok = !(power > 0.0f) && !(e < FR_E255);                 // forward.cu:347-357
+	g.a_un = __builtin_amdgcn_exp2f(e);
+	g.alpha = fminf(0.99f, g.a_un);
+	g.om1 = 1.f - g.alpha;
+	return g;
+}
+// forward.cu:358-366 for one pair.  Returns `kill`; con = ok && !kill.  The colour prefix is summed in double: pass 2 needs the
+// SUFFIX X - Cg_<=i of deep contributors (a small difference of two numbers of order one) as exactly as the reference's
+// back-to-front accumulation has it, and both passes must add the same fp32 terms.
+__device__ __forceinline__ bool fr_prefix_update(const FrPairAlpha& g, float cg, float& T, double& Cg, bool& con)
+{
+	const float test_T = T * g.om1;
+	const bool kill = g.ok && (test_T < 0.0001f);
+	con = g.ok && !kill;
+	const float term = cg * (g.alpha * T);
+	Cg = con ? Cg + (double)term : Cg;
+	T = con ? test_T : T;
+	return kill;
+}
+
+// The footprint of one candidate over a wave's BW x BH pixels as a bit mask (bit = row * BW + column): row by row,
+// power(dx, dy) >= thr  <=>  cx dx^2 + 2 cy dy dx + (cz dy^2 + 2 thr) <= 0, an interval in dx (d = mean - pixel), widened by
+// 1 % + 0.01 px so that it stays a superset of the exact pair test.
+template <int BW, int BH>
+__device__ __forceinline__ unsigned long long fr_footprint_mask(const float4& a, const float4& b4, float strip_lo, float tile_x0)
+{
+	unsigned long long emask = 0ull;
+	const float ax = a.x, ay = a.y;
+	const uint32_t eb = __float_as_uint(a.z);
+	const float ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+	const float ahy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+	const float acx = -2.0f * b4.x, acy = -b4.y, acz = -2.0f * b4.z;
+	const float athr = -(5.541263545158426f + 0.6931471805599453f * a.w) - 0.01f;   // -ln(255 opacity) - 0.01
+	const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
+	const float racx = __builtin_amdgcn_rcpf(acx);
+#pragma unroll
+	for (unsigned r = 0; r < (unsigned)BH; r++)
+	{
+		const float dy = ay - (strip_lo + (float)r);
+		float lo = ax - ahx, hi2 = ax + ahx;                  // box fallback (unknown / degenerate conic)
+		bool any_px = fabsf(dy) <= ahy;
+		if (quad_ok)
+		{
+			const float hb = acy * dy;
+			const float cq = acz * dy * dy + 2.0f * athr;
+			const float disc = hb * hb - acx * cq;
+			any_px = any_px && (disc >= 0.f);
+			const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
+			const float dlo = (-hb - sq) * racx, dhi = (-hb + sq) * racx;
+			lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;
+		}
+		const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, (float)(BW - 1));
+		if (any_px && c0f <= c1f)
+		{
+			const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f;
+			const unsigned long long cols = (unsigned long long)(((2u << c1) - 1u) & ~((1u << c0) - 1u));
+			emask |= cols << (BW * r);
+		}
+	}
+	return emask;
+}
+
+// The stream / chunk skeleton of k_fisher_tile_v3 for one pass of one wave; NQ = float4 of recq parked per candidate.
+// body(m, id, emask) runs once per chunk of m <= 64 candidates: lane l < m holds candidate l (its index `id`, its footprint
+// `emask` over the wave's pixels) and has parked its record at ent[l]; the body sets `done` for finished pixels.
+template <int BW, int BH, int NQ, class Body>
+__device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, uint32_t n, const float4* __restrict__ rec,
+                                              const float4* __restrict__ rq, uint32_t* wq, float4 (*ent)[FR_ENT_F4],
+                                              int lane, float strip_lo, float tile_x0, bool& done, Body body)
+{
+	const float strip_hi = strip_lo + (float)(BH - 1), tile_x1 = tile_x0 + (float)(BW - 1);
+	uint32_t qh = 0, qn = 0;
+	uint32_t id1 = 0, id2 = 0;
+	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[2 * (size_t)id1]; }
+	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
+	uint32_t base = 0;
+	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	while (!all_done)
+	{
+		while (qn < 64u && base < n)
+		{
+			const uint32_t idc = id1; const float4 rc = r1;
+			id1 = id2;
+			if (base + 64 + lane < n) r1 = rec[2 * (size_t)id2];
+			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
+			const uint32_t eb = __float_as_uint(rc.z);
+			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			const bool ov = (base + lane < n) && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi)
+			                && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc;
+			qn += (uint32_t)__popcll(om);
+			base += 64;
+		}
+		if (qn == 0) break;
+		const uint32_t m = qn < 64u ? qn : 64u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		unsigned long long emask = 0ull;
+		uint32_t my_id = 0;
+		if ((uint32_t)lane < m)
+		{
+			my_id = wq[(qh + lane) & (FR_QCAP - 1)];
+			const float4 a = rec[2 * (size_t)my_id], b4 = rec[2 * (size_t)my_id + 1];
+			ent[lane][0] = a; ent[lane][1] = b4;
+#pragma unroll
+			for (int k = 0; k < NQ; k++) ent[lane][2 + k] = rq[4 * (size_t)my_id + k];
+			emask = fr_footprint_mask<BW, BH>(a, b4, strip_lo, tile_x0);
+		}
+		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		body(m, my_id, emask);
+		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	}
+}
+
+// Sums of four per-lane values over the wave with a halving butterfly (7 additions instead of 24), on the VALU only (DPP
+// quad permutes and row rotations, then the gfx950 row / half swaps): on return lane l holds the total of column
+// 2 (l & 1) + ((l >> 1) & 1).
+template <int CTRL> __device__ __forceinline__ float fr_dpp(float x)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fr_wave_sum4(float v0, float v1, float v2, float v3, int lane)
+{
+	const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+	const float s0 = (b0 ? v2 : v0) + fr_dpp<0xB1>(b0 ? v0 : v2);            // quad_perm [1, 0, 3, 2]: lane ^ 1
+	const float s1 = (b0 ? v3 : v1) + fr_dpp<0xB1>(b0 ? v1 : v3);
+	float r = (b1 ? s1 : s0) + fr_dpp<0x4E>(b1 ? s0 : s1);                    // quad_perm [2, 3, 0, 1]: lane ^ 2
+	r += fr_dpp<0x124>(r);                                                      // row_ror:4
+	r += fr_dpp<0x128>(r);                                                      // row_ror:8 -> the row's sum of this lane's column
+	{
+		const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r), __float_as_uint(r), false, false);   // rows 0 <-> 1, 2 <-> 3
+		r = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+	}
+	{
+		const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);   // halves
+		r = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+	}
+	return r;
+}
+
+template <int BW, int BH, bool UNIFORM>
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
+{
+	static_assert(BW * BH == 64 && 16 % BW == 0, "a wave owns 64 pixels of the tile");
+	__shared__ uint32_t s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][64][FR_ENT_F4];
+	__shared__ float s_acc[4][64][4];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	constexpr int WPR = 16 / BW;
+	const uint32_t bx0 = tx * FR_BLOCK_X + (uint32_t)(wave % WPR) * BW, by0 = ty * FR_BLOCK_Y + (uint32_t)(wave / WPR) * BH;
+	const uint32_t pxx = bx0 + (uint32_t)(lane % BW), pxy = by0 + (uint32_t)(lane / BW);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* rec = (const float4*)(p.splat + vP);
+	const float4* rq = recq + vP * 4;
+	uint32_t* wq = s_q[wave];
+	float4 (*ent)[FR_ENT_F4] = s_ent[wave];
+	float (*acc)[4] = s_acc[wave];
+	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];
+	const float strip_lo = (float)by0, tile_x0 = (float)bx0;
+
+	// ---- pass 1: X.  Every pixel-lane walks its own candidates (the set bits of the transposed footprint masks).
+	float T = 1.0f;
+	double Cg = 0.0;
+	bool done = !inside;
+	fr_strip_pass<BW, BH, 0>(gk, n, rec, rq, wq, ent, lane, strip_lo, tile_x0, done,
+		[&](uint32_t, uint32_t, unsigned long long emask) {
+			unsigned long long mask = fr_wave_transpose64(emask, lane);
+			if (done) mask = 0ull;
+			while (mask != 0ull)
+			{
+				const int j = __ffsll((long long)mask) - 1;
+				mask &= mask - 1ull;
+				const uint32_t addr = ent_lds + (uint32_t)j * (FR_ENT_F4 * 16);
+				fr_v4f a, b4;
+				asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b4) : "v"(addr) : "memory");
+				const FrPairAlpha g = fr_pair_alpha(a, b4, pfx, pfy);
+				bool con;
+				if (fr_prefix_update(g, b4.w, T, Cg, con)) { mask = 0ull; done = true; }
+			}
+		});
+	const double X = Cg + (double)(T * (p.bg[0] + p.bg[1] + p.bg[2]));
+
+	// ---- pass 2: the squares
+	T = 1.0f; Cg = 0.0;
+	done = !inside;
+	const float dL2 = f.dL * f.dL;
+	float* dst = f.out_H + (size_t)v * f.outH_stride;
+	// one (pixel, candidate) pair: replays the recurrences and returns the pair's four squared columns (zero when it does not contribute)
+	auto pair = [&](uint32_t addr, bool part, float& h0, float& h1, float& h2, float& h3, bool& con) -> bool {
+		FrWalkRec r;
+		asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+		             "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
+		             "s_waitcnt lgkmcnt(0)"
+		             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2), "=&v"(r.q3) : "v"(addr) : "memory");
+		FrPairAlpha g = fr_pair_alpha(r.a, r.b4, pfx, pfy);
+		g.ok = g.ok && part;
+		const float T_i = T;
+		const bool kill = fr_prefix_update(g, r.b4.w, T, Cg, con);
+		{
+#pragma clang fp contract(fast)
+			const float bi = __builtin_amdgcn_rcpf(g.om1);
+			const float dLda = T_i * r.b4.w - (float)(X - Cg) * bi;               // backward.cu:1000-1016 with the suffix written as X - prefix
+			const float w = g.a_un * dLda;
+			const float w2 = con ? w * w : 0.f;
+			const float dx = g.dx, dy = g.dy;
+			const float u0 = r.b4.x * dx + (r.b4.x * dx + r.b4.y * dy);
+			const float u1 = 2.0f * (r.b4.z * dy) + r.b4.y * dx;
+			const float u2 = dx * dx, u3 = dx * dy, u4 = dy * dy;
+			// record: {A'[0][0..3]} {A'[0][4], A'[1][0..2]} {A'[1][3..4], A'[2][0..1]} {A'[2][2..4], 1/opacity^2}
+			const float l0 = r.q0.x * u0 + r.q0.y * u1 + r.q0.z * u2 + r.q0.w * u3 + r.q1.x * u4;
+			const float l1 = r.q1.y * u0 + r.q1.z * u1 + r.q1.w * u2 + r.q2.x * u3 + r.q2.y * u4;
+			const float l2 = r.q2.z * u0 + r.q2.w * u1 + r.q3.x * u2 + r.q3.y * u3 + r.q3.z * u4;
+			h0 = w2 * (l0 * l0); h1 = w2 * (l1 * l1); h2 = w2 * (l2 * l2); h3 = w2 * r.q3.w;
+		}
+		return kill;
+	};
+	fr_strip_pass<BW, BH, 4>(gk, n, rec, rq, wq, ent, lane, strip_lo, tile_x0, done,
+		[&](uint32_t m, uint32_t my_id, unsigned long long emask) {
+			*(float4*)&acc[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if constexpr (UNIFORM)
+			{
+				// Full chip: the wave takes the chunk's candidates one at a time, all pixel-lanes together.  ds_add_f32 costs ~3 cycles
+				// per LANE on MI355X whatever the addresses (tools/lds_atomic_rate.hip) and the LDS pipe is shared by the CU's sixteen
+				// waves, so per-lane walks adding four values per pair spend 3/4 of the pass there; here the four columns are summed
+				// over the wave by a butterfly on the VALU and written once.
+				unsigned long long alive = __builtin_amdgcn_ballot_w64(!done);
+				const uint32_t em_lo = (uint32_t)emask, em_hi = (uint32_t)(emask >> 32);
+				for (uint32_t j = 0; j < m && alive != 0ull; j++)
+				{
+					const unsigned long long em = ((((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)em_hi, (int)j)) << 32)
+					                               | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)em_lo, (int)j)) & alive;
+					if (em == 0ull) continue;
+					float h0, h1, h2, h3; bool con;
+					const bool kill = pair(ent_lds + j * (FR_ENT_F4 * 16), ((em >> lane) & 1ull) != 0ull, h0, h1, h2, h3, con);
+					if (kill) done = true;
+					alive &= ~__builtin_amdgcn_ballot_w64(kill);
+					if (__builtin_amdgcn_ballot_w64(con) == 0ull) continue;
+					const float tot = fr_wave_sum4(h0, h1, h2, h3, lane);
+					if (lane < 4) acc[j][((lane & 1) << 1) | (lane >> 1)] = tot;
+				}
+			}
+			else
+			{
+				// Few workgroups per CU (a handful of views): the longest tile sets the time, so every pixel-lane walks its own
+				// candidates (a third of the steps) and pays the LDS atomics
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				unsigned long long mask = fr_wave_transpose64(emask, lane);
+				if (done) mask = 0ull;
+				while (mask != 0ull)
+				{
+					const int j = __ffsll((long long)mask) - 1;
+					mask &= mask - 1ull;
+					float h0, h1, h2, h3; bool con;
+					const bool kill = pair(ent_lds + (uint32_t)j * (FR_ENT_F4 * 16), true, h0, h1, h2, h3, con);
+					if (con)
+					{
+						atomicAdd(&acc[j][0], h0); atomicAdd(&acc[j][1], h1); atomicAdd(&acc[j][2], h2); atomicAdd(&acc[j][3], h3);
+					}
+					if (kill) { mask = 0ull; done = true; }
+				}
+				__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			// flush: consecutive lanes on consecutive columns of one Gaussian
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+			{
+				const int flat = i * 64 + lane;
+				const int e = flat >> 2, c = flat & 3;
+				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)my_id);
+				const float a = ((uint32_t)e < m) ? acc[e][c] * dL2 : 0.f;
+				if (a != 0.f) atomicAdd(dst + (size_t)id_e * 4 + c, a);
+			}
+			__builtin_amdgcn_wave_barrier();
+		});
 }
 
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
@@ -3006,10 +3336,10 @@ static FrSideStream& fr_side_stream(int which = 0)
 }
 
 // Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
-// k_preprocess_views; with the single-view front end, k_fisher_records beside scan / scatter / sort on the second side stream).
-struct FrScorerPlan { int columns; FrRecordArgs ra; };
+// k_preprocess_views; with the single-view front end, k_fisher_records after k_scatter_keys, beside the sorts, on the second side stream).
+struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; };     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
 template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed);
-template <int C, bool LIST> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
+template <int C, bool LIST, bool FORM_A> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
 
 static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, const FrScorerPlan* plan = nullptr)
 {
@@ -3053,6 +3383,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
 		if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		else if (plan->form_a) hipLaunchKernelGGL((k_preprocess_views<-4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else hipLaunchKernelGGL((k_preprocess_views<11, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		if ((rc = fr_check_launch("k_preprocess_views"))) return rc;
@@ -3061,20 +3392,6 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	{
 		hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
 		if ((rc = fr_check_launch("k_preprocess"))) return rc;
-		if (plan)
-		{
-			FrSideStream& s2 = fr_side_stream(1);
-			const bool forked2 = s2.ok && hipEventRecord(s2.fork, s) == hipSuccess && hipStreamWaitEvent(s2.stream, s2.fork, 0) == hipSuccess;
-			hipStream_t rs = forked2 ? s2.stream : s;
-			if (plan->columns == 4) hipLaunchKernelGGL((k_fisher_records<4, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
-			else hipLaunchKernelGGL((k_fisher_records<11, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
-			if ((rc = fr_check_launch("k_fisher_records"))) return rc;
-			if (forked2)
-			{
-				if (hipEventRecord(s2.join, s2.stream) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipEventRecord(join 2) failed");
-				side2 = &s2;
-			}
-		}
 	}
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
 	                   p.key_capacity, p.status, multi ? (int*)nullptr : p.num_rendered, p.big_list);
@@ -3082,6 +3399,23 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	if (multi) hipLaunchKernelGGL(k_scatter_vis, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	else hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
+	// Single-view front end in a records mode: k_fisher_records turns the FrSplat records into the scorer's form IN PLACE, so it
+	// may only start once k_scatter_keys has read their depths; it then runs beside the sorts, which touch the keys only.
+	if (plan && !multi)
+	{
+		FrSideStream& s2 = fr_side_stream(1);
+		const bool forked2 = s2.ok && hipEventRecord(s2.fork, s) == hipSuccess && hipStreamWaitEvent(s2.stream, s2.fork, 0) == hipSuccess;
+		hipStream_t rs = forked2 ? s2.stream : s;
+		if (plan->form_a) hipLaunchKernelGGL((k_fisher_records<4, false, true>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
+		else if (plan->columns == 4) hipLaunchKernelGGL((k_fisher_records<4, false, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
+		else hipLaunchKernelGGL((k_fisher_records<11, false, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
+		if ((rc = fr_check_launch("k_fisher_records"))) return rc;
+		if (forked2)
+		{
+			if (hipEventRecord(s2.join, s2.stream) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipEventRecord(join 2) failed");
+			side2 = &s2;
+		}
+	}
 	// The three sort tiers touch disjoint tile segments.  The 1024-thread tier has few, long-running workgroups (one per
 	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
 	FrSideStream& side = fr_side_stream();
@@ -3444,6 +3778,28 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 	}
 }
 
+#define FR_V3H_UNIFORM_FROM 1024     // (tile, view) workgroups from which the wave-uniform pass 2 wins (MI355X: 256 CUs x 4 resident)
+// out_H mode with 4 columns and a constant upstream gradient: two front-to-back passes over the records
+static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, hipStream_t s)
+{
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (g_prof_on)
+	{
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, s);
+	}
+	// per-lane walks + LDS atomics while the chip is not full (their LDS pipe is then a CU's own), the wave-uniform form beyond;
+	// FR_DEBUG_MODE=20 / 21 force one or the other (A/B runs)
+	const bool uniform = f.debug_mode == 20 ? false : f.debug_mode == 21 ? true : (long long)p.T * p.V > FR_V3H_UNIFORM_FROM;
+	if (uniform) hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	else hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, false>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	if (g_prof_on)
+	{
+		(void)hipEventRecord(ev1, s);
+		g_prof_events.push_back(std::make_pair(ev0, ev1));
+	}
+}
+
 template <int C>
 static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t* fallback, hipStream_t s)
 {
@@ -3531,13 +3887,17 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	// score-only (H_inv, no out_H, constant upstream gradient): records + one front-to-back pass; FR_DEBUG_MODE=9 keeps
 	// the second-generation two-pass kernel for A/B runs
 	const bool v3 = fc->H_inv && !fc->out_H && !fc->dL_dpix_image && f.debug_mode != 1 && f.debug_mode != 9;
+	// the diagonal itself (out_H, no H_inv, 4 columns, constant upstream gradient): records + two front-to-back passes
+	const bool v3h = !fc->H_inv && fc->out_H && !fc->dL_dpix_image && fc->columns == 4 && f.debug_mode != 1 && f.debug_mode != 9;
 	FrScorerPlan plan;
+	plan.form_a = v3h;
 	plan.columns = fc->columns;
 	plan.ra.H_inv = fc->H_inv; plan.ra.hinv_stride = fc->H_inv_view_stride;
 	plan.ra.packed = (const float*)(ws + L.packed); plan.ra.recq = (float4*)(ws + L.recq);
-	if ((rc = fr_bin_pipeline(p, g, s, v3 ? &plan : nullptr))) return rc;
+	if ((rc = fr_bin_pipeline(p, g, s, (v3 || v3h) ? &plan : nullptr))) return rc;
 
 	if (v3) fr_launch_fisher_v3(p, f, plan.ra.recq, s);
+	else if (v3h) fr_launch_fisher_v3h(p, f, plan.ra.recq, s);
 	else if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
 	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
 

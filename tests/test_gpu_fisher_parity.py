@@ -398,7 +398,7 @@ def test_more_tiles_than_the_lds_histogram_holds(gpu, oracle):
     H_o, _ = oracle.compute_hessian(cam, w2c, act["means3D"], act["rgb_colors"], act["rotations"], act["opacities"], act["scales"])
     assert_close(cur.cpu().numpy(), H_o, 1e-4, "cur_H", atol_frac=1e-7)
     # score-only mode on this image size: the scorer's records come from k_fisher_records (visibility from radii, on the side
-    # stream beside scan / scatter / sort) instead of phase C of the multi-view front end
+    # stream beside the sorts, after the scatter has read the depths it rewrites) instead of phase C of the multi-view front end
     Hi = torch.rand((P, 4), generator=torch.Generator().manual_seed(1)) * 2.0 + 0.1
     got = sc.run(torch.from_numpy(np.stack([w2c, w2c])).to(gpu), H_inv=Hi.to(gpu))["scores"].cpu().numpy()
     want_s = float((H_o.astype(np.float64) * Hi.numpy().astype(np.float64)).sum())

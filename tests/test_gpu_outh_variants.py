@@ -1,0 +1,38 @@
+"""-m gpu: the two forms of the second pass of k_fisher_tile_v3h (per-lane walks with LDS atomics below
+FR_V3H_UNIFORM_FROM workgroups, the wave-uniform loop with a butterfly sum above) and the second-generation kernel
+(FR_DEBUG_MODE=9), each forced in a fresh process on the same scene and held to the oracle's compute_hessian."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_util import assert_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, V, W, H, SEED = 2500, 3, 96, 80, 17
+
+
+@pytest.fixture(scope="module")
+def want(oracle):
+    from fisher_rast import synthetic
+    act = {k: v.numpy() for k, v in synthetic.activate(synthetic.room_shell(P, seed=SEED)).items()}
+    cam = oracle.setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4))
+    w2cs = synthetic.invert_rigid(synthetic.candidate_poses(V, seed=SEED)).numpy()
+    return np.stack([oracle.compute_hessian(cam, w, act["means3D"], act["rgb_colors"], act["rotations"], act["opacities"],
+                                            act["scales"])[0] for w in w2cs])
+
+
+@pytest.mark.parametrize("mode,what", [("20", "per-lane walks + LDS atomics"), ("21", "wave-uniform loop"), ("9", "two-pass kernel of round 1")])
+def test_forced_out_h_kernel_matches_the_oracle(gpu, want, tmp_path, mode, what):
+    out = str(tmp_path / f"h_{mode}.npy")
+    env = dict(os.environ, FR_DEBUG_MODE=mode)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "outh_variant_probe.py"), out, str(P), str(V), str(W), str(H), str(SEED)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    assert got.shape == want.shape
+    for v in range(V):
+        assert_close(got[v], want[v], 1e-4, f"{what}: cur_H[{v}]", atol_frac=1e-7)
