@@ -105,6 +105,7 @@ struct FrParams {
 	struct FrVisEntry* vis_list; // [V][blocks][FR_THREADS * G] compacted visible splats of each preprocess workgroup
 	uint32_t* vis_n;             // [V][blocks] their number
 	int VC;                      // views per preprocess workgroup
+	int legacy_sort;             // FR_DEBUG_MODE=6: the LDS-resident sort network of round 1 (A/B runs)
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -762,7 +763,220 @@ __device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid, con
 	}
 }
 
-// Segments of up to FR_SORT_SMALL_KEYS keys: one workgroup per (tile, view), 16 KiB of LDS.
+// ---------------------------------------------------------------------------------------------------------
+// Register-resident form of the same network.  A wave holds a run of 64 K keys: key[r] of lane l is element r * 64 + l, so
+// loads and stores are coalesced, strides of 64 and more inside the run are compare-exchanges between registers of one lane
+// and strides below 64 are exchanges between lanes (ds_bpermute: the LDS crossbar, no memory, no bank conflicts).  Only the
+// stages that join the runs of different waves go through LDS memory: 3 round trips for 4 waves (10 for 16) instead of one
+// per two network stages (36 for 2048 keys) -- the LDS-resident form was LDS-bound with half its cycles lost to bank
+// conflicts (profiles/r02_final_pmc_3.txt).  Elements at or beyond n are +inf in registers and never stored.
+__device__ __forceinline__ uint64_t fr_shfl64(uint64_t v, int src_lane)
+{
+	const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+	const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+	return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
+}
+__device__ __forceinline__ void fr_take(uint64_t& mine, uint64_t other, bool keepmin)
+{
+	const bool take = (other < mine) == keepmin;
+	mine = take ? other : mine;
+}
+// Exchanges between lanes on the VALU (the LDS crossbar of ds_bpermute is the bottleneck otherwise: ~800 of them per wave
+// for 2048 keys): DPP quad permutes / row rotations / mirrors inside a row of 16, gfx950's row and half swaps beyond.
+template <int CTRL>
+__device__ __forceinline__ uint64_t fr_dpp64(uint64_t v)
+{
+	// (mov_dpp: no `old` operand to initialise -- every lane has a source under these controls)
+	const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+	return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
+}
+// key <-> the key of lane ^ 16 (ROWS = 16) or lane ^ 32 (ROWS = 32): after the swap both lanes of a pair hold the same two
+// values (a, b), so the result is min or max of the two whatever side the lane is on.
+template <int ROWS>
+__device__ __forceinline__ void fr_take_rows(uint64_t& key, bool keepmin)
+{
+	const uint32_t l = (uint32_t)key, h = (uint32_t)(key >> 32);
+	uint64_t a, b;
+	if constexpr (ROWS == 16)
+	{
+		const auto tl = __builtin_amdgcn_permlane16_swap(l, l, false, false);
+		const auto th = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+		a = ((uint64_t)th[0] << 32) | tl[0]; b = ((uint64_t)th[1] << 32) | tl[1];
+	}
+	else
+	{
+		const auto tl = __builtin_amdgcn_permlane32_swap(l, l, false, false);
+		const auto th = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+		a = ((uint64_t)th[0] << 32) | tl[0]; b = ((uint64_t)th[1] << 32) | tl[1];
+	}
+	key = ((b < a) == keepmin) ? b : a;
+}
+
+// flip stage of block size k = 2^S inside the wave's run (S <= 6 + log2 K): element e <-> e ^ (k - 1).
+// (Stage and stride numbers are template parameters so that every register index is a constant.)
+template <int K, int S>
+__device__ __forceinline__ void fr_wave_flip(uint64_t (&key)[K], int lane)
+{
+	if constexpr (S <= 4)
+	{
+		// mirrors inside a row: quad_perm [1,0,3,2], quad_perm [3,2,1,0], row_half_mirror, row_mirror
+		constexpr int CTRL = S == 1 ? 0xB1 : S == 2 ? 0x1B : S == 3 ? 0x141 : 0x140;
+		const bool keepmin = (lane & (1 << (S - 1))) == 0;
+#pragma unroll
+		for (int r = 0; r < K; r++) fr_take(key[r], fr_dpp64<CTRL>(key[r]), keepmin);
+	}
+	else if constexpr (S <= 6)
+	{
+		constexpr int k = 1 << S;
+		const int src = lane ^ (k - 1);
+		const bool keepmin = (lane & (k >> 1)) == 0;
+#pragma unroll
+		for (int r = 0; r < K; r++) fr_take(key[r], fr_shfl64(key[r], src), keepmin);
+	}
+	else
+	{
+		constexpr int kr = 1 << (S - 6);               // registers per block
+		const int src = lane ^ 63;
+#pragma unroll
+		for (int r = 0; r < K; r++)
+		{
+			if ((r & (kr >> 1)) == 0)                    // r: lower half of its block, rp: its mirror in the upper half
+			{
+				const int rp = r ^ (kr - 1);
+				const uint64_t lo = key[r], hi = key[rp];
+				fr_take(key[r], fr_shfl64(hi, src), true);
+				fr_take(key[rp], fr_shfl64(lo, src), false);
+			}
+		}
+	}
+}
+// half-cleaners of strides 2^T, 2^(T-1), ..., 1 inside the wave's run: element e <-> e ^ j
+template <int K, int T>
+__device__ __forceinline__ void fr_wave_xor_down(uint64_t (&key)[K], int lane)
+{
+	if constexpr (T >= 0)
+	{
+		if constexpr (T < 6)
+		{
+			const bool keepmin = (lane & (1 << T)) == 0;
+#pragma unroll
+			for (int r = 0; r < K; r++)
+			{
+				if constexpr (T == 0) fr_take(key[r], fr_dpp64<0xB1>(key[r]), keepmin);                       // quad_perm [1,0,3,2]
+				else if constexpr (T == 1) fr_take(key[r], fr_dpp64<0x4E>(key[r]), keepmin);                  // quad_perm [2,3,0,1]
+				else if constexpr (T == 2) fr_take(key[r], fr_dpp64<0x141>(fr_dpp64<0x1B>(key[r])), keepmin); // (i ^ 3) ^ 7 = i ^ 4
+				else if constexpr (T == 3) fr_take(key[r], fr_dpp64<0x128>(key[r]), keepmin);                 // row_ror:8
+				else if constexpr (T == 4) fr_take_rows<16>(key[r], keepmin);
+				else fr_take_rows<32>(key[r], keepmin);
+			}
+		}
+		else
+		{
+			constexpr int jr = 1 << (T - 6);
+#pragma unroll
+			for (int r = 0; r < K; r++)
+				if ((r & jr) == 0) fr_cx(key[r], key[r | jr]);
+		}
+		fr_wave_xor_down<K, T - 1>(key, lane);
+	}
+}
+// stages 2 .. min(n_pad, 2^S) of the network on the wave's own run
+template <int K, int S>
+__device__ __forceinline__ void fr_wave_stages(uint64_t (&key)[K], uint32_t n_pad, int lane)
+{
+	if constexpr (S >= 1)
+	{
+		fr_wave_stages<K, S - 1>(key, n_pad, lane);
+		if ((1u << S) <= n_pad)
+		{
+			fr_wave_flip<K, S>(key, lane);
+			fr_wave_xor_down<K, S - 2>(key, lane);
+		}
+	}
+}
+template <int K> struct FrLog2 { static constexpr int value = K == 1 ? 0 : K == 2 ? 1 : K == 4 ? 2 : K == 8 ? 3 : 4; };
+
+// One wave, n <= 64 K keys of a segment in global memory.
+template <int K>
+__device__ __forceinline__ void fr_sort_wave_segment(uint64_t* __restrict__ gk, uint32_t n, int lane)
+{
+	uint64_t key[K];
+#pragma unroll
+	for (int r = 0; r < K; r++) { const uint32_t i = (uint32_t)(r * 64 + lane); key[r] = i < n ? gk[i] : ~0ull; }
+	uint32_t n_pad = 1;
+	while (n_pad < n) n_pad <<= 1;
+	fr_wave_stages<K, 6 + FrLog2<K>::value>(key, n_pad, lane);
+#pragma unroll
+	for (int r = 0; r < K; r++) { const uint32_t i = (uint32_t)(r * 64 + lane); if (i < n) gk[i] = key[r]; }
+}
+
+// The stages that join the runs of the NW waves of a workgroup (block size 2^SW runs), through LDS memory.
+template <int K, int NW, int TW>
+__device__ __forceinline__ void fr_wg_xor_down(uint64_t (&key)[K], uint64_t* sk, int w, int lane)
+{
+	if constexpr (TW >= 0)
+	{
+		constexpr int RUN = 64 * K, jw = 1 << TW;
+		const uint32_t base = (uint32_t)(w * RUN);
+#pragma unroll
+		for (int r = 0; r < K; r++) sk[base + (uint32_t)(r * 64 + lane)] = key[r];
+		__syncthreads();
+		const uint32_t pbase = (uint32_t)((w ^ jw) * RUN);
+		const bool keepmin = (w & jw) == 0;
+#pragma unroll
+		for (int r = 0; r < K; r++) fr_take(key[r], sk[pbase + (uint32_t)(r * 64 + lane)], keepmin);
+		__syncthreads();
+		fr_wg_xor_down<K, NW, TW - 1>(key, sk, w, lane);
+	}
+}
+template <int K, int NW, int SW>
+__device__ __forceinline__ void fr_wg_stages(uint64_t (&key)[K], uint64_t* sk, uint32_t n_pad, int w, int lane)
+{
+	if constexpr (SW >= 1)
+	{
+		fr_wg_stages<K, NW, SW - 1>(key, sk, n_pad, w, lane);
+		constexpr int RUN = 64 * K, kw = 1 << SW;
+		if (((uint32_t)RUN << SW) <= n_pad)            // uniform over the workgroup
+		{
+			// flip across the runs: element (w, r, l) <-> (w ^ (kw - 1), K - 1 - r, 63 - l)
+			const uint32_t base = (uint32_t)(w * RUN);
+#pragma unroll
+			for (int r = 0; r < K; r++) sk[base + (uint32_t)(r * 64 + lane)] = key[r];
+			__syncthreads();
+			const uint32_t pbase = (uint32_t)((w ^ (kw - 1)) * RUN);
+			const bool keepmin = (w & (kw >> 1)) == 0;
+#pragma unroll
+			for (int r = 0; r < K; r++) fr_take(key[r], sk[pbase + (uint32_t)((K - 1 - r) * 64 + (63 - lane))], keepmin);
+			__syncthreads();
+			fr_wg_xor_down<K, NW, SW - 2>(key, sk, w, lane);               // strides of whole runs
+			fr_wave_xor_down<K, 5 + FrLog2<K>::value>(key, lane);          // ... and the rest of the stage inside the runs
+		}
+	}
+}
+
+// NW waves (a whole workgroup), n <= NW * 64 * K keys; sk = NW * 64 * K keys of LDS.
+template <int K, int NW>
+__device__ __forceinline__ void fr_sort_wg_segment(uint64_t* sk, uint64_t* __restrict__ gk, uint32_t n, int tid)
+{
+	static_assert(NW == 4 || NW == 16, "4 or 16 waves");
+	constexpr int RUN = 64 * K;
+	const int lane = tid & 63;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t base = (uint32_t)(w * RUN);
+	uint64_t key[K];
+#pragma unroll
+	for (int r = 0; r < K; r++) { const uint32_t i = base + (uint32_t)(r * 64 + lane); key[r] = i < n ? gk[i] : ~0ull; }
+	uint32_t n_pad = 1;
+	while (n_pad < n) n_pad <<= 1;
+	fr_wave_stages<K, 6 + FrLog2<K>::value>(key, n_pad, lane);
+	fr_wg_stages<K, NW, (NW == 4 ? 2 : 4)>(key, sk, n_pad, w, lane);
+#pragma unroll
+	for (int r = 0; r < K; r++) { const uint32_t i = base + (uint32_t)(r * 64 + lane); if (i < n) gk[i] = key[r]; }
+}
+
+// Segments of up to FR_SORT_SMALL_KEYS keys: one workgroup per (tile, view).  Up to 512 keys the first wave sorts alone
+// (no barrier at all; the other three leave at once), beyond that the four waves hold 256 K keys, K = 4 or 8.
 __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 {
 	if (p.status[1]) return;
@@ -774,16 +988,31 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 	const uint32_t n = p.tile_cnt[vt];
 	if (n < 2 || n > (uint32_t)FR_SORT_SMALL_KEYS) return;
 	uint64_t* gk = p.keys + p.tile_off[vt];
-	for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
-	__syncthreads();
-	fr_bitonic(skeys, n, tid, FR_THREADS);
-	for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+	if (p.legacy_sort)
+	{
+		for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
+		__syncthreads();
+		fr_bitonic(skeys, n, tid, FR_THREADS);
+		for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+		return;
+	}
+	if (n <= 512u)
+	{
+		if (tid >= 64) return;
+		if (n <= 64u) fr_sort_wave_segment<1>(gk, n, tid);
+		else if (n <= 128u) fr_sort_wave_segment<2>(gk, n, tid);
+		else if (n <= 256u) fr_sort_wave_segment<4>(gk, n, tid);
+		else fr_sort_wave_segment<8>(gk, n, tid);
+		return;
+	}
+	if (n <= 1024u) fr_sort_wg_segment<4, 4>(skeys, gk, n, tid);
+	else fr_sort_wg_segment<8, 4>(skeys, gk, n, tid);
 }
 
 // Larger segments are listed by k_scan_tiles and sorted by two grid-stride kernels over that list:
-//   k_sort_mid_tiles : FR_SORT_SMALL_KEYS < n <= FR_SORT_MID_KEYS, 256 threads, 32 KiB of LDS (several workgroups per CU)
-//   k_sort_big_tiles : n > FR_SORT_MID_KEYS, 1024 threads, 128 KiB of LDS; beyond FR_SORT_BIG_KEYS the same network runs
-//                      on global memory (__syncthreads orders the workgroup's own accesses).
+//   k_sort_mid_tiles : FR_SORT_SMALL_KEYS < n <= FR_SORT_MID_KEYS, 256 threads x 16 keys, 32 KiB of LDS
+//   k_sort_big_tiles : n > FR_SORT_MID_KEYS, 1024 threads x 8 or 16 keys, 128 KiB of LDS; beyond FR_SORT_BIG_KEYS the
+//                      LDS-resident form of the network runs on global memory (__syncthreads orders the workgroup's own accesses).
 __global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
 {
 	if (p.status[1]) return;
@@ -797,10 +1026,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
 		if (n > (uint32_t)FR_SORT_MID_KEYS) continue;
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
-		for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
-		__syncthreads();
-		fr_bitonic(skeys, n, tid, FR_THREADS);
-		for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+		if (p.legacy_sort)
+		{
+			for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
+			__syncthreads();
+			fr_bitonic(skeys, n, tid, FR_THREADS);
+			for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
+		}
+		else fr_sort_wg_segment<16, 4>(skeys, gk, n, tid);
 	}
 }
 
@@ -817,14 +1050,16 @@ __global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
 		if (n <= (uint32_t)FR_SORT_MID_KEYS) continue;
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
-		if (n <= (uint32_t)FR_SORT_BIG_KEYS)
+		if (n > (uint32_t)FR_SORT_BIG_KEYS) fr_bitonic(gk, n, tid, 1024);
+		else if (p.legacy_sort)
 		{
 			for (uint32_t i = tid; i < n; i += 1024) skeys[i] = gk[i];
 			__syncthreads();
 			fr_bitonic(skeys, n, tid, 1024);
 			for (uint32_t i = tid; i < n; i += 1024) gk[i] = skeys[i];
 		}
-		else fr_bitonic(gk, n, tid, 1024);
+		else if (n <= 8192u) fr_sort_wg_segment<8, 16>(skeys, gk, n, tid);
+		else fr_sort_wg_segment<16, 16>(skeys, gk, n, tid);
 	}
 }
 
@@ -3273,7 +3508,6 @@ static int fr_validate(const fr_raster_cfg* cfg, const fr_gaussians* g, const ch
 
 static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gaussians* g, int V)
 {
-	p.vis_list = nullptr; p.vis_n = nullptr; p.VC = 1;
 	memset(&p, 0, sizeof(p));
 	p.P = cfg->P; p.V = V; p.W = cfg->image_width; p.H = cfg->image_height;
 	p.gx = (uint32_t)((p.W + 15) / 16); p.gy = (uint32_t)((p.H + 15) / 16); p.T = (int)(p.gx * p.gy);
@@ -3284,6 +3518,8 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 	p.bg = cfg->bg; p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
 	p.means3D = g->means3D; p.colors = g->colors_precomp; p.shs = g->shs; p.opac = g->opacities;
 	p.scales = g->scales; p.rots = g->rotations;
+	p.VC = 1;
+	p.legacy_sort = fr_debug_mode() == 6;
 }
 
 // Launches cov3d, preprocess, scan, scatter, sort for V views.  p must carry the carved buffers.
