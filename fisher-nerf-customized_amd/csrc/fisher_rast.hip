@@ -764,10 +764,12 @@ __device__ __forceinline__ void fr_bitonic(KeyPtr keys, uint32_t n, int tid, con
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Register-resident form of the same network.  A wave holds a run of 64 K keys: key[r] of lane l is element r * 64 + l, so
-// loads and stores are coalesced, strides of 64 and more inside the run are compare-exchanges between registers of one lane
-// and strides below 64 are exchanges between lanes (ds_bpermute: the LDS crossbar, no memory, no bank conflicts).  Only the
-// stages that join the runs of different waves go through LDS memory: 3 round trips for 4 waves (10 for 16) instead of one
+// Register-resident form of the same network.  A wave holds a run of 64 K keys: key[r] of lane l is element l * K + r, so
+// every stride below K -- the last log2 K passes of EVERY stage, and the first log2 K stages whole -- is a compare-exchange
+// between registers of one lane (2.5 instructions per key), and the strides from K up to the run are exchanges between lanes
+// on the VALU (5 instructions per key: DPP inside a row of 16 lanes, v_permlane16/32_swap across rows; tools/valu_ceiling
+// --sort prices them).  Only the stages that join the runs of different waves go through LDS memory (stored there as
+// [register][lane], conflict-free): 3 round trips for 4 waves (10 for 16) instead of one
 // per two network stages (36 for 2048 keys) -- the LDS-resident form was LDS-bound with half its cycles lost to bank
 // conflicts (profiles/r02_final_pmc_3.txt).  Elements at or beyond n are +inf in registers and never stored.
 __device__ __forceinline__ uint64_t fr_shfl64(uint64_t v, int src_lane)
@@ -813,40 +815,57 @@ __device__ __forceinline__ void fr_take_rows(uint64_t& key, bool keepmin)
 	key = ((b < a) == keepmin) ? b : a;
 }
 
+template <int K> struct FrLog2 { static constexpr int value = K == 1 ? 0 : K == 2 ? 1 : K == 4 ? 2 : K == 8 ? 3 : 4; };
+// key <-> the key of lane ^ 2^M
+template <int M>
+__device__ __forceinline__ void fr_take_lane_xor(uint64_t& key, bool keepmin)
+{
+	if constexpr (M == 0) fr_take(key, fr_dpp64<0xB1>(key), keepmin);                       // quad_perm [1,0,3,2]
+	else if constexpr (M == 1) fr_take(key, fr_dpp64<0x4E>(key), keepmin);                  // quad_perm [2,3,0,1]
+	else if constexpr (M == 2) fr_take(key, fr_dpp64<0x141>(fr_dpp64<0x1B>(key)), keepmin); // (i ^ 3) ^ 7 = i ^ 4
+	else if constexpr (M == 3) fr_take(key, fr_dpp64<0x128>(key), keepmin);                 // row_ror:8
+	else if constexpr (M == 4) fr_take_rows<16>(key, keepmin);
+	else fr_take_rows<32>(key, keepmin);
+}
+// the key of lane ^ (2^M - 1): mirrors inside a row by DPP (quad_perm [1,0,3,2], quad_perm [3,2,1,0], row_half_mirror,
+// row_mirror), across rows by ds_bpermute
+template <int M>
+__device__ __forceinline__ uint64_t fr_lane_mirror(uint64_t key, int lane)
+{
+	if constexpr (M == 1) return fr_dpp64<0xB1>(key);
+	else if constexpr (M == 2) return fr_dpp64<0x1B>(key);
+	else if constexpr (M == 3) return fr_dpp64<0x141>(key);
+	else if constexpr (M == 4) return fr_dpp64<0x140>(key);
+	else return fr_shfl64(key, lane ^ ((1 << M) - 1));
+}
+
 // flip stage of block size k = 2^S inside the wave's run (S <= 6 + log2 K): element e <-> e ^ (k - 1).
 // (Stage and stride numbers are template parameters so that every register index is a constant.)
 template <int K, int S>
 __device__ __forceinline__ void fr_wave_flip(uint64_t (&key)[K], int lane)
 {
-	if constexpr (S <= 4)
+	constexpr int LK = FrLog2<K>::value;
+	if constexpr (S <= LK)
 	{
-		// mirrors inside a row: quad_perm [1,0,3,2], quad_perm [3,2,1,0], row_half_mirror, row_mirror
-		constexpr int CTRL = S == 1 ? 0xB1 : S == 2 ? 0x1B : S == 3 ? 0x141 : 0x140;
-		const bool keepmin = (lane & (1 << (S - 1))) == 0;
+		constexpr int kr = 1 << S;                     // registers per block: mirror pairs inside the lane
 #pragma unroll
-		for (int r = 0; r < K; r++) fr_take(key[r], fr_dpp64<CTRL>(key[r]), keepmin);
-	}
-	else if constexpr (S <= 6)
-	{
-		constexpr int k = 1 << S;
-		const int src = lane ^ (k - 1);
-		const bool keepmin = (lane & (k >> 1)) == 0;
-#pragma unroll
-		for (int r = 0; r < K; r++) fr_take(key[r], fr_shfl64(key[r], src), keepmin);
+		for (int r = 0; r < K; r++)
+			if ((r & (kr >> 1)) == 0) fr_cx(key[r], key[r ^ (kr - 1)]);
 	}
 	else
 	{
-		constexpr int kr = 1 << (S - 6);               // registers per block
-		const int src = lane ^ 63;
-#pragma unroll
-		for (int r = 0; r < K; r++)
+		// blocks of 2^M lanes: element (l, r) <-> (l ^ (2^M - 1), K - 1 - r); the half an element is in is a lane bit
+		constexpr int M = S - LK;
+		const bool keepmin = (lane & (1 << (M - 1))) == 0;
+		if constexpr (K == 1) fr_take(key[0], fr_lane_mirror<M>(key[0], lane), keepmin);
+		else
 		{
-			if ((r & (kr >> 1)) == 0)                    // r: lower half of its block, rp: its mirror in the upper half
+#pragma unroll
+			for (int r = 0; r < K / 2; r++)
 			{
-				const int rp = r ^ (kr - 1);
-				const uint64_t lo = key[r], hi = key[rp];
-				fr_take(key[r], fr_shfl64(hi, src), true);
-				fr_take(key[rp], fr_shfl64(lo, src), false);
+				const uint64_t lo = key[r], hi = key[K - 1 - r];
+				fr_take(key[r], fr_lane_mirror<M>(hi, lane), keepmin);
+				fr_take(key[K - 1 - r], fr_lane_mirror<M>(lo, lane), keepmin);
 			}
 		}
 	}
@@ -855,25 +874,18 @@ __device__ __forceinline__ void fr_wave_flip(uint64_t (&key)[K], int lane)
 template <int K, int T>
 __device__ __forceinline__ void fr_wave_xor_down(uint64_t (&key)[K], int lane)
 {
+	constexpr int LK = FrLog2<K>::value;
 	if constexpr (T >= 0)
 	{
-		if constexpr (T < 6)
+		if constexpr (T >= LK)
 		{
-			const bool keepmin = (lane & (1 << T)) == 0;
+			const bool keepmin = (lane & (1 << (T - LK))) == 0;
 #pragma unroll
-			for (int r = 0; r < K; r++)
-			{
-				if constexpr (T == 0) fr_take(key[r], fr_dpp64<0xB1>(key[r]), keepmin);                       // quad_perm [1,0,3,2]
-				else if constexpr (T == 1) fr_take(key[r], fr_dpp64<0x4E>(key[r]), keepmin);                  // quad_perm [2,3,0,1]
-				else if constexpr (T == 2) fr_take(key[r], fr_dpp64<0x141>(fr_dpp64<0x1B>(key[r])), keepmin); // (i ^ 3) ^ 7 = i ^ 4
-				else if constexpr (T == 3) fr_take(key[r], fr_dpp64<0x128>(key[r]), keepmin);                 // row_ror:8
-				else if constexpr (T == 4) fr_take_rows<16>(key[r], keepmin);
-				else fr_take_rows<32>(key[r], keepmin);
-			}
+			for (int r = 0; r < K; r++) fr_take_lane_xor<T - LK>(key[r], keepmin);
 		}
 		else
 		{
-			constexpr int jr = 1 << (T - 6);
+			constexpr int jr = 1 << T;
 #pragma unroll
 			for (int r = 0; r < K; r++)
 				if ((r & jr) == 0) fr_cx(key[r], key[r | jr]);
@@ -895,7 +907,6 @@ __device__ __forceinline__ void fr_wave_stages(uint64_t (&key)[K], uint32_t n_pa
 		}
 	}
 }
-template <int K> struct FrLog2 { static constexpr int value = K == 1 ? 0 : K == 2 ? 1 : K == 4 ? 2 : K == 8 ? 3 : 4; };
 
 // One wave, n <= 64 K keys of a segment in global memory.
 template <int K>
@@ -903,12 +914,12 @@ __device__ __forceinline__ void fr_sort_wave_segment(uint64_t* __restrict__ gk, 
 {
 	uint64_t key[K];
 #pragma unroll
-	for (int r = 0; r < K; r++) { const uint32_t i = (uint32_t)(r * 64 + lane); key[r] = i < n ? gk[i] : ~0ull; }
+	for (int r = 0; r < K; r++) { const uint32_t i = (uint32_t)(lane * K + r); key[r] = i < n ? gk[i] : ~0ull; }
 	uint32_t n_pad = 1;
 	while (n_pad < n) n_pad <<= 1;
 	fr_wave_stages<K, 6 + FrLog2<K>::value>(key, n_pad, lane);
 #pragma unroll
-	for (int r = 0; r < K; r++) { const uint32_t i = (uint32_t)(r * 64 + lane); if (i < n) gk[i] = key[r]; }
+	for (int r = 0; r < K; r++) { const uint32_t i = (uint32_t)(lane * K + r); if (i < n) gk[i] = key[r]; }
 }
 
 // The stages that join the runs of the NW waves of a workgroup (block size 2^SW runs), through LDS memory.
@@ -966,13 +977,13 @@ __device__ __forceinline__ void fr_sort_wg_segment(uint64_t* sk, uint64_t* __res
 	const uint32_t base = (uint32_t)(w * RUN);
 	uint64_t key[K];
 #pragma unroll
-	for (int r = 0; r < K; r++) { const uint32_t i = base + (uint32_t)(r * 64 + lane); key[r] = i < n ? gk[i] : ~0ull; }
+	for (int r = 0; r < K; r++) { const uint32_t i = base + (uint32_t)(lane * K + r); key[r] = i < n ? gk[i] : ~0ull; }
 	uint32_t n_pad = 1;
 	while (n_pad < n) n_pad <<= 1;
 	fr_wave_stages<K, 6 + FrLog2<K>::value>(key, n_pad, lane);
 	fr_wg_stages<K, NW, (NW == 4 ? 2 : 4)>(key, sk, n_pad, w, lane);
 #pragma unroll
-	for (int r = 0; r < K; r++) { const uint32_t i = base + (uint32_t)(r * 64 + lane); if (i < n) gk[i] = key[r]; }
+	for (int r = 0; r < K; r++) { const uint32_t i = base + (uint32_t)(lane * K + r); if (i < n) gk[i] = key[r]; }
 }
 
 // Segments of up to FR_SORT_SMALL_KEYS keys: one workgroup per (tile, view).  Up to 512 keys the first wave sorts alone
@@ -1005,6 +1016,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 		else fr_sort_wave_segment<8>(gk, n, tid);
 		return;
 	}
+	// (one wave with 16 keys per lane for 513 .. 1024 keys: measured slower, 0.107 against 0.097 ms)
 	if (n <= 1024u) fr_sort_wg_segment<4, 4>(skeys, gk, n, tid);
 	else fr_sort_wg_segment<8, 4>(skeys, gk, n, tid);
 }

@@ -4,6 +4,7 @@
 //   build: hipcc -O3 --offload-arch=gfx950 -o tools/_build/valu_ceiling tools/valu_ceiling.hip
 //   run:   tools/_build/valu_ceiling            (prints one JSON line per configuration)
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -59,6 +60,64 @@ __global__ __launch_bounds__(256) void k_stream(float* out, int iters, float c1,
 #pragma unroll
 	for (int k = 0; k < ILP; k++) s += a[k];
 	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Issue cost of the instructions the register-resident sort is made of (inline asm so that the compiler cannot rewrite them):
+// OP 0: v_cmp_lt_u64 + v_cndmask_b32   1: v_cmp_lt_u32 + v_cndmask_b32   2: v_mov_b32_dpp row_ror:8   3: v_permlane32_swap_b32
+template <int OP>
+__global__ __launch_bounds__(256) void k_stream_asm(float* out, int iters)
+{
+	uint32_t a0 = threadIdx.x, a1 = threadIdx.x * 3u, a2 = threadIdx.x * 5u, a3 = threadIdx.x * 7u;
+	uint32_t b0 = 11u + threadIdx.x, b1 = 13u, b2 = 17u + threadIdx.x, b3 = 19u;
+	for (int i = 0; i < iters; i++)
+	{
+#pragma unroll
+		for (int r = 0; r < 32; r++)
+		{
+			if (OP == 0)
+				asm volatile("v_cmp_lt_u64 vcc, %[x], %[y]\n\tv_cndmask_b32 %[a], %[a], %[c], vcc\n\t"
+				             "v_cmp_lt_u64 vcc, %[y], %[x]\n\tv_cndmask_b32 %[c], %[c], %[a], vcc"
+				             : [a] "+v"(a0), [c] "+v"(a2) : [x] "v"((uint64_t)a1 << 32 | b0), [y] "v"((uint64_t)a3 << 32 | b2) : "vcc");
+			else if (OP == 1)
+				asm volatile("v_cmp_lt_u32 vcc, %[x], %[y]\n\tv_cndmask_b32 %[a], %[a], %[c], vcc\n\t"
+				             "v_cmp_lt_u32 vcc, %[y], %[x]\n\tv_cndmask_b32 %[c], %[c], %[a], vcc"
+				             : [a] "+v"(a0), [c] "+v"(a2) : [x] "v"(a1), [y] "v"(a3) : "vcc");
+			else if (OP == 2)
+				asm volatile("v_mov_b32_dpp %[a], %[b] row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[c], %[d] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_mov_b32_dpp %[b], %[a] row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[d], %[c] row_ror:8 row_mask:0xf bank_mask:0xf"
+				             : [a] "+v"(a0), [b] "+v"(a1), [c] "+v"(a2), [d] "+v"(a3));
+			else
+				asm volatile("v_permlane32_swap_b32 %[a], %[b]\n\tv_permlane32_swap_b32 %[c], %[d]\n\t"
+				             "v_permlane32_swap_b32 %[a], %[c]\n\tv_permlane32_swap_b32 %[b], %[d]"
+				             : [a] "+v"(a0), [b] "+v"(a1), [c] "+v"(a2), [d] "+v"(a3));
+		}
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + b0 + b1 + b2 + b3);
+}
+template <int OP>
+static void run_asm(const char* name, int waves_per_simd, float* d_out)
+{
+	const int iters = 500;
+	dim3 grid(256 * waves_per_simd), block(256);
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	hipLaunchKernelGGL((k_stream_asm<OP>), grid, block, 0, 0, d_out, iters);
+	CHECK(hipDeviceSynchronize());
+	float best = 1e30f;
+	for (int rep = 0; rep < 5; rep++)
+	{
+		CHECK(hipEventRecord(e0, 0));
+		hipLaunchKernelGGL((k_stream_asm<OP>), grid, block, 0, 0, d_out, iters);
+		CHECK(hipEventRecord(e1, 0));
+		CHECK(hipEventSynchronize(e1));
+		float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		if (ms < best) best = ms;
+	}
+	const double wave_insts = (double)grid.x * 4.0 * iters * 32.0 * 4.0;
+	const double per_simd_per_ns = wave_insts / 1024.0 / (best * 1e6);
+	printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"wave_insts_per_ns_per_simd\": %.4f, "
+	       "\"cycles_per_inst_at_2.4GHz\": %.3f, \"chip_wave_insts_per_s\": %.4e}\n",
+	       name, waves_per_simd, best, per_simd_per_ns, 2.4 / per_simd_per_ns, per_simd_per_ns * 1e9 * 1024.0);
 }
 
 template <int ILP, int KIND>
@@ -124,6 +183,19 @@ int main(int argc, char** argv)
 		run<8, 0>("v_fma_f32", 5, d_out, 1);
 		run<1, 0>("v_fma_f32 dependent chain", 5, d_out, 1);
 		run<8, 3>("v_fma_f32 with three VGPR sources", 5, d_out, 1);
+		CHECK(hipFree(d_out));
+		return 0;
+	}
+	if (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 's')
+	{
+		// --sort: the instruction mix of the register-resident key sort
+		for (int w : { 1, 4 })
+		{
+			run_asm<0>("v_cmp_lt_u64 + v_cndmask_b32 (two instructions counted)", w, d_out);
+			run_asm<1>("v_cmp_lt_u32 + v_cndmask_b32 (two instructions counted)", w, d_out);
+			run_asm<2>("v_mov_b32_dpp row_ror:8", w, d_out);
+			run_asm<3>("v_permlane32_swap_b32", w, d_out);
+		}
 		CHECK(hipFree(d_out));
 		return 0;
 	}
