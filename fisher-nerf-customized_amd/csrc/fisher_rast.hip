@@ -1610,7 +1610,7 @@ template <int C, bool HAS_HINV, bool HAS_OUTH>
 __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C == 4 ? (HAS_OUTH ? 4 : 5) : (HAS_OUTH ? 2 : 4)))) void k_fisher_tile_v2(FrParams p, FrFisherArgs f, const float* __restrict__ packed,
                                                                uint8_t* __restrict__ fallback)
 {
-	__shared__ float s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];
+	__shared__ double s_acc[HAS_OUTH ? 4 : 1][HAS_OUTH ? C : 1][64];   // double: ds_add_f64 is ~20x faster than ds_add_f32 on MI355X (tools/lds_atomic_rate.hip)
 	constexpr int PS = FrPackSize<C>::value;
 	// per-entry registers of pass 2: rgb[3], A'[15], (Cm'[21]), k3, [H_inv columns]
 	// QFORM (score only): the weighted sum of squared leaves is a quadratic form in u',
@@ -1627,7 +1627,10 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 	constexpr int HO = KO + 1;                    // offset of the H_inv columns
 	constexpr bool FOLD3 = HAS_HINV && !HAS_OUTH; // H_inv[3] folded into k3
 	constexpr int NB = QFORM ? 19 : HO + (HAS_HINV ? C : 0);
-	__shared__ uint16_t s_wl[4][FR_WCAP];
+	// per-wave contributor list; the all-leaves mode trades 256 entries of it for a second resident workgroup (its 25 double
+	// accumulators per candidate take 50 KiB: 80 KiB in all)
+	constexpr int WCAP = FULL ? FR_WCAP - 256 : FR_WCAP;
+	__shared__ uint16_t s_wl[4][WCAP];
 	__shared__ float s_red[4];
 	__shared__ int s_ovf;
 
@@ -1724,14 +1727,14 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 					T = contrib ? test_T : T;
 					last = contrib ? (wcnt + 1) : last;      // 1 + index in THIS wave's list of the pixel's last contributor
 					// every lane stores the same value to the same address: no exec-mask juggling for a one-lane write
-					if (wcnt < FR_WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
+					if (wcnt < WCAP) s_wl[wave][wcnt] = (uint16_t)(base + j);
 					wcnt = __builtin_amdgcn_readfirstlane(wcnt + 1);
 				}
 			}
 		}
 		if (done_m == ~0ull) break;
 	}
-	if (lane == 0 && wcnt > FR_WCAP) s_ovf = 1;
+	if (lane == 0 && wcnt > WCAP) s_ovf = 1;
 	__syncthreads();
 	if (s_ovf)
 	{
@@ -1791,7 +1794,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 		if constexpr (HAS_OUTH)
 		{
 #pragma unroll
-			for (int c = 0; c < C; c++) s_acc[wave][c][lane] = 0.f;
+			for (int c = 0; c < C; c++) s_acc[wave][c][lane] = 0.0;
 		}
 		if (lane < m)
 		{
@@ -2059,7 +2062,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 					if (has)
 					{
 #pragma unroll
-						for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], w2 * leaf2[c]);
+						for (int c = 0; c < C; c++) atomicAdd(&s_acc[wave][c][j], (double)(w2 * leaf2[c]));
 					}
 				}
 			}
@@ -2077,7 +2080,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 				const int flat = i * 64 + lane;
 				const int e = flat / C, c = flat - e * C;
 				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)my_id);
-				const float a = (e < m) ? s_acc[wave][c][e] : 0.f;
+				const float a = (e < m) ? (float)s_acc[wave][c][e] : 0.f;
 				if constexpr (FULL)
 				{
 					// column -> (gradient tensor, row stride, offset): means3D 0-2, opacity 3, scales 4-6, rotations 7-10, colours 11-13,
@@ -2527,7 +2530,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 //   pass 1   transmittance / colour prefix only (recA + recB, two ds_read_b128 per pair)            -> X per pixel
 //   pass 2   replays the recurrences (same arithmetic, hence the same contributor set), forms
 //            w = opacity G (T_i cg_i - (X - Cg_<=i) b_i) and the three mean rows A'_r . u' of the record (A-form of
-//            fr_fisher_record_one), squares and adds them into wave-private LDS accumulators [column][candidate];
+//            fr_fisher_record_one), squares and adds them into wave-private LDS accumulators [column][candidate] -- in
+//            DOUBLE, because ds_add_f64 costs 8.6 cycles per wave instruction on distinct addresses where ds_add_f32 costs
+//            ~190 whatever the addresses (tools/lds_atomic_rate.hip; with float accumulators 3/4 of this pass was LDS time);
 //   flush    per chunk, consecutive lanes on consecutive columns of one Gaussian (global float atomics into out_H).
 // Against k_fisher_tile_v2 this drops the per-chunk Jacobian chains (they are in the records), the contributor lists and
 // the back-to-front order.
@@ -2657,40 +2662,16 @@ __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, u
 	}
 }
 
-// Sums of four per-lane values over the wave with a halving butterfly (7 additions instead of 24), on the VALU only (DPP
-// quad permutes and row rotations, then the gfx950 row / half swaps): on return lane l holds the total of column
-// 2 (l & 1) + ((l >> 1) & 1).
-template <int CTRL> __device__ __forceinline__ float fr_dpp(float x)
-{
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float fr_wave_sum4(float v0, float v1, float v2, float v3, int lane)
-{
-	const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-	const float s0 = (b0 ? v2 : v0) + fr_dpp<0xB1>(b0 ? v0 : v2);            // quad_perm [1, 0, 3, 2]: lane ^ 1
-	const float s1 = (b0 ? v3 : v1) + fr_dpp<0xB1>(b0 ? v1 : v3);
-	float r = (b1 ? s1 : s0) + fr_dpp<0x4E>(b1 ? s0 : s1);                    // quad_perm [2, 3, 0, 1]: lane ^ 2
-	r += fr_dpp<0x124>(r);                                                      // row_ror:4
-	r += fr_dpp<0x128>(r);                                                      // row_ror:8 -> the row's sum of this lane's column
-	{
-		const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r), __float_as_uint(r), false, false);   // rows 0 <-> 1, 2 <-> 3
-		r = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-	}
-	{
-		const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);   // halves
-		r = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-	}
-	return r;
-}
-
-template <int BW, int BH, bool UNIFORM>
+template <int BW, int BH>
 __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
 {
 	static_assert(BW * BH == 64 && 16 % BW == 0, "a wave owns 64 pixels of the tile");
 	__shared__ uint32_t s_q[4][FR_QCAP];
 	__shared__ float4 s_ent[4][64][FR_ENT_F4];
-	__shared__ float s_acc[4][64][4];
+	// accumulators [column][candidate] in DOUBLE: ds_add_f64 takes 8.6 cycles per wave instruction on distinct addresses (3 per
+	// lane on equal ones), ds_add_f32 ~190 whatever the addresses (tools/lds_atomic_rate.hip)
+	__shared__ double s_acc[4][4][64];
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2710,7 +2691,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	const float4* rq = recq + vP * 4;
 	uint32_t* wq = s_q[wave];
 	float4 (*ent)[FR_ENT_F4] = s_ent[wave];
-	float (*acc)[4] = s_acc[wave];
+	double (*acc)[64] = s_acc[wave];
 	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];
 	const float strip_lo = (float)by0, tile_x0 = (float)bx0;
 
@@ -2742,14 +2723,13 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	const float dL2 = f.dL * f.dL;
 	float* dst = f.out_H + (size_t)v * f.outH_stride;
 	// one (pixel, candidate) pair: replays the recurrences and returns the pair's four squared columns (zero when it does not contribute)
-	auto pair = [&](uint32_t addr, bool part, float& h0, float& h1, float& h2, float& h3, bool& con) -> bool {
+	auto pair = [&](uint32_t addr, float& h0, float& h1, float& h2, float& h3, bool& con) -> bool {
 		FrWalkRec r;
 		asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
 		             "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
 		             "s_waitcnt lgkmcnt(0)"
 		             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2), "=&v"(r.q3) : "v"(addr) : "memory");
-		FrPairAlpha g = fr_pair_alpha(r.a, r.b4, pfx, pfy);
-		g.ok = g.ok && part;
+		const FrPairAlpha g = fr_pair_alpha(r.a, r.b4, pfx, pfy);
 		const float T_i = T;
 		const bool kill = fr_prefix_update(g, r.b4.w, T, Cg, con);
 		{
@@ -2772,51 +2752,25 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	};
 	fr_strip_pass<BW, BH, 4>(gk, n, rec, rq, wq, ent, lane, strip_lo, tile_x0, done,
 		[&](uint32_t m, uint32_t my_id, unsigned long long emask) {
-			*(float4*)&acc[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-			if constexpr (UNIFORM)
+#pragma unroll
+			for (int c = 0; c < 4; c++) acc[c][lane] = 0.0;
+			// every pixel-lane walks its own candidates (the set bits of the transposed footprint masks)
+			unsigned long long mask = fr_wave_transpose64(emask, lane);
+			if (done) mask = 0ull;
+			while (mask != 0ull)
 			{
-				// Full chip: the wave takes the chunk's candidates one at a time, all pixel-lanes together.  ds_add_f32 costs ~3 cycles
-				// per LANE on MI355X whatever the addresses (tools/lds_atomic_rate.hip) and the LDS pipe is shared by the CU's sixteen
-				// waves, so per-lane walks adding four values per pair spend 3/4 of the pass there; here the four columns are summed
-				// over the wave by a butterfly on the VALU and written once.
-				unsigned long long alive = __builtin_amdgcn_ballot_w64(!done);
-				const uint32_t em_lo = (uint32_t)emask, em_hi = (uint32_t)(emask >> 32);
-				for (uint32_t j = 0; j < m && alive != 0ull; j++)
+				const int j = __ffsll((long long)mask) - 1;
+				mask &= mask - 1ull;
+				float h0, h1, h2, h3; bool con;
+				const bool kill = pair(ent_lds + (uint32_t)j * (FR_ENT_F4 * 16), h0, h1, h2, h3, con);
+				if (con)
 				{
-					const unsigned long long em = ((((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)em_hi, (int)j)) << 32)
-					                               | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)em_lo, (int)j)) & alive;
-					if (em == 0ull) continue;
-					float h0, h1, h2, h3; bool con;
-					const bool kill = pair(ent_lds + j * (FR_ENT_F4 * 16), ((em >> lane) & 1ull) != 0ull, h0, h1, h2, h3, con);
-					if (kill) done = true;
-					alive &= ~__builtin_amdgcn_ballot_w64(kill);
-					if (__builtin_amdgcn_ballot_w64(con) == 0ull) continue;
-					const float tot = fr_wave_sum4(h0, h1, h2, h3, lane);
-					if (lane < 4) acc[j][((lane & 1) << 1) | (lane >> 1)] = tot;
+					atomicAdd(&acc[0][j], (double)h0); atomicAdd(&acc[1][j], (double)h1);
+					atomicAdd(&acc[2][j], (double)h2); atomicAdd(&acc[3][j], (double)h3);
 				}
+				if (kill) { mask = 0ull; done = true; }
 			}
-			else
-			{
-				// Few workgroups per CU (a handful of views): the longest tile sets the time, so every pixel-lane walks its own
-				// candidates (a third of the steps) and pays the LDS atomics
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				unsigned long long mask = fr_wave_transpose64(emask, lane);
-				if (done) mask = 0ull;
-				while (mask != 0ull)
-				{
-					const int j = __ffsll((long long)mask) - 1;
-					mask &= mask - 1ull;
-					float h0, h1, h2, h3; bool con;
-					const bool kill = pair(ent_lds + (uint32_t)j * (FR_ENT_F4 * 16), true, h0, h1, h2, h3, con);
-					if (con)
-					{
-						atomicAdd(&acc[j][0], h0); atomicAdd(&acc[j][1], h1); atomicAdd(&acc[j][2], h2); atomicAdd(&acc[j][3], h3);
-					}
-					if (kill) { mask = 0ull; done = true; }
-				}
-				__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
-			}
+			__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			// flush: consecutive lanes on consecutive columns of one Gaussian
@@ -2826,7 +2780,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 				const int flat = i * 64 + lane;
 				const int e = flat >> 2, c = flat & 3;
 				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)my_id);
-				const float a = ((uint32_t)e < m) ? acc[e][c] * dL2 : 0.f;
+				const float a = ((uint32_t)e < m) ? (float)acc[c][e] * dL2 : 0.f;
 				if (a != 0.f) atomicAdd(dst + (size_t)id_e * 4 + c, a);
 			}
 			__builtin_amdgcn_wave_barrier();
@@ -3065,7 +3019,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 	constexpr int NCH = PAIR ? 6 : 3;
 	constexpr int NACC = PAIR ? 14 : 9;          // m2x, m2y, qx, qy, qw, dcolor[NCH], dopacity, (m2x, m2y of the second image)
 	__shared__ uint16_t s_wl[4][FR_WCAP];
-	__shared__ float s_acc[4][NACC][64];
+	__shared__ double s_acc[4][NACC][64];        // double: ds_add_f64 is ~20x faster than ds_add_f32 on MI355X (tools/lds_atomic_rate.hip)
 	__shared__ int s_ovf;
 
 	if (p.status[1]) return;
@@ -3184,7 +3138,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 #pragma unroll
 		for (int c = 0; c < NCH; c++) col[c] = 0.f;
 #pragma unroll
-		for (int c = 0; c < NACC; c++) s_acc[wave][c][lane] = 0.f;
+		for (int c = 0; c < NACC; c++) s_acc[wave][c][lane] = 0.0;
 		if (lane < m)
 		{
 			kk = (int)wl[hi - 1 - lane];
@@ -3274,16 +3228,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 				const float dG_ddelx = -gdx * cx - gdy * cy, dG_ddely = -gdy * cz - gdx * cy;
 				// screen-space gradient of the first image (of the only image when !PAIR)
 				const float oa = PAIR ? o * da : dL_dG;
-				atomicAdd(&s_acc[wave][0][j], oa * dG_ddelx * ddelx_dx); atomicAdd(&s_acc[wave][1][j], oa * dG_ddely * ddely_dy);
-				atomicAdd(&s_acc[wave][2][j], -0.5f * gdx * dx * dL_dG); atomicAdd(&s_acc[wave][3][j], -0.5f * gdx * dy * dL_dG);
-				atomicAdd(&s_acc[wave][4][j], -0.5f * gdy * dy * dL_dG);
+				atomicAdd(&s_acc[wave][0][j], (double)(oa * dG_ddelx * ddelx_dx)); atomicAdd(&s_acc[wave][1][j], (double)(oa * dG_ddely * ddely_dy));
+				atomicAdd(&s_acc[wave][2][j], (double)(-0.5f * gdx * dx * dL_dG)); atomicAdd(&s_acc[wave][3][j], (double)(-0.5f * gdx * dy * dL_dG));
+				atomicAdd(&s_acc[wave][4][j], (double)(-0.5f * gdy * dy * dL_dG));
 #pragma unroll
-				for (int c = 0; c < NCH; c++) atomicAdd(&s_acc[wave][5 + c][j], wcol * g[c]);
-				atomicAdd(&s_acc[wave][5 + NCH][j], G * dL_dalpha);
+				for (int c = 0; c < NCH; c++) atomicAdd(&s_acc[wave][5 + c][j], (double)(wcol * g[c]));
+				atomicAdd(&s_acc[wave][5 + NCH][j], (double)(G * dL_dalpha));
 				if constexpr (PAIR)
 				{
 					const float ob = o * db;
-					atomicAdd(&s_acc[wave][12][j], ob * dG_ddelx * ddelx_dx); atomicAdd(&s_acc[wave][13][j], ob * dG_ddely * ddely_dy);
+					atomicAdd(&s_acc[wave][12][j], (double)(ob * dG_ddelx * ddelx_dx)); atomicAdd(&s_acc[wave][13][j], (double)(ob * dG_ddely * ddely_dy));
 				}
 			}
 		}
@@ -3292,23 +3246,23 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 		{
 			const size_t id = my_id;
 			float a;
-			if ((a = s_acc[wave][0][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id, a);
-			if ((a = s_acc[wave][1][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id + 1, a);
-			if ((a = s_acc[wave][2][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id, a);
-			if ((a = s_acc[wave][3][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 1, a);
-			if ((a = s_acc[wave][4][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 3, a);
-			if ((a = s_acc[wave][5][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id, a);
-			if ((a = s_acc[wave][6][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 1, a);
-			if ((a = s_acc[wave][7][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 2, a);
+			if ((a = (float)s_acc[wave][0][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id, a);
+			if ((a = (float)s_acc[wave][1][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id + 1, a);
+			if ((a = (float)s_acc[wave][2][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id, a);
+			if ((a = (float)s_acc[wave][3][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 1, a);
+			if ((a = (float)s_acc[wave][4][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 3, a);
+			if ((a = (float)s_acc[wave][5][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id, a);
+			if ((a = (float)s_acc[wave][6][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 1, a);
+			if ((a = (float)s_acc[wave][7][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 2, a);
 			if constexpr (PAIR)
 			{
-				if ((a = s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id, a);
-				if ((a = s_acc[wave][9][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 1, a);
-				if ((a = s_acc[wave][10][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 2, a);
-				if ((a = s_acc[wave][12][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id, a);
-				if ((a = s_acc[wave][13][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id + 1, a);
+				if ((a = (float)s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id, a);
+				if ((a = (float)s_acc[wave][9][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 1, a);
+				if ((a = (float)s_acc[wave][10][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 2, a);
+				if ((a = (float)s_acc[wave][12][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id, a);
+				if ((a = (float)s_acc[wave][13][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id + 1, a);
 			}
-			if ((a = s_acc[wave][5 + NCH][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
+			if ((a = (float)s_acc[wave][5 + NCH][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
 		}
 	}
 }
@@ -4026,7 +3980,6 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 	}
 }
 
-#define FR_V3H_UNIFORM_FROM 1024     // (tile, view) workgroups from which the wave-uniform pass 2 wins (MI355X: 256 CUs x 4 resident)
 // out_H mode with 4 columns and a constant upstream gradient: two front-to-back passes over the records
 static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, hipStream_t s)
 {
@@ -4036,11 +3989,7 @@ static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, hipS
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
 		(void)hipEventRecord(ev0, s);
 	}
-	// per-lane walks + LDS atomics while the chip is not full (their LDS pipe is then a CU's own), the wave-uniform form beyond;
-	// FR_DEBUG_MODE=20 / 21 force one or the other (A/B runs)
-	const bool uniform = f.debug_mode == 20 ? false : f.debug_mode == 21 ? true : (long long)p.T * p.V > FR_V3H_UNIFORM_FROM;
-	if (uniform) hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
-	else hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, false>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);

@@ -1,6 +1,6 @@
 """Helper of test_gpu_outh_variants.py (not a test): per-view diagonals of a small synthetic scene through fr_fisher_views'
 out_H mode, written to the .npy named on the command line.  The parent sets FR_DEBUG_MODE (read once per process by the
-library) to force one form of the second pass of k_fisher_tile_v3h."""
+library) to pick the kernel generation."""
 import os
 import sys
 
