@@ -35,7 +35,7 @@ import torch         # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-BYTES_PER_TILE_INSTANCE = 8 + 32 + 64   # k_fisher_tile_v3: sorted key + {recA, recB} + recQ, each moved once
+BYTES_PER_TILE_INSTANCE = 8 + 32 + 52   # k_fisher_tile_v3: sorted key + {recA, recB} + the 13 floats of recQ it uses, each moved once
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -441,7 +441,7 @@ def main():
         R = float(int(last["status"].cpu()[0]))
         T = ((W + 15) // 16) * ((H + 15) // 16)
         # algorithmic bytes of ONE k_fisher_tile_v3 launch: per tile instance the sorted key (8 B), the
-        # 32-byte {recA, recB} record and the 64-byte recQ record, each moved once; plus one partial score per (view, tile)
+        # 32-byte {recA, recB} record and the 52 used bytes of the recQ record, each moved once; plus one partial score per (view, tile)
         kern_bytes = (R * BYTES_PER_TILE_INSTANCE + 4.0 * V * T) / launches_per_step
         ach = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
         # whole-path algorithmic bytes per view, SURVEY.md 8(d)

@@ -464,7 +464,7 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 //            this workgroup's compact list, which is all k_scatter_vis reads (no radii array, no idle lanes).
 // The arithmetic per pair is fr_preprocess_one's, so radii / rects / depths are bit-identical to k_preprocess.
 //   phase C  (RC != 0: score-only mode) the workgroup walks the compact lists it has just written and turns every visible
-//            (view, Gaussian) into the scorer's 96-byte record (fr_fisher_record_one) while the splat records are still in L2.
+//            (view, Gaussian) into the scorer's record (fr_fisher_record_one) while the splat records are still in L2.
 template <int RC, bool PHASE_C>
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrRecordArgs ra)
 {
@@ -2129,7 +2129,9 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 // and folded with H_inv into the 5x5 form Q -- is computed ONCE per visible (view, Gaussian) by k_fisher_records instead of
 // once per (strip, list entry) inside the tile kernel, and stored as 96 bytes:
 //     recA {x, y, ext, log2(opacity)}   recB {-conic.x/2, -conic.y, -conic.z/2, cg}    (in place of the FrSplat record)
-//     recQ {Q'[15], k3}                                                                 (64 B, [V][P])
+//     recQ {c02 c03 c04 c11 | c12 c13 c20 c21 | c22 c30 c31 c40 | k3}                   (64 B, [V][P]): the pair's geometry factor
+//          u'^T Q u' + k3 written out as a polynomial in (dx, dy) -- terms of degree 2..4 only, 12 coefficients -- which the walk
+//          evaluates by Horner's rule in 14 operations (26 for the quadratic form)
 // ---------------------------------------------------------------------------------------------------------
 // REWRITE: the (view, Gaussian) record still holds the rasteriser's FrSplat and is turned into {recA, recB} here (stand-alone
 // k_fisher_records); otherwise the front end has already written {recA, recB} and only recQ is produced.
@@ -2153,7 +2155,8 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
 	float A[3][5];
 	float B[6][3];
-	fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr);
+	float cov2d[3];
+	fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr, cov2d);
 	// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
 	// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
 	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
@@ -2228,15 +2231,39 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 			qf[q++] = (i == j) ? acc : 2.0f * acc;
 		}
 	const float inv_o = __builtin_amdgcn_rcpf(opacity);
-	qf[15] = inv_o * inv_o * hv[3];                      // dL_dopacity = G dL_dalpha = w / opacity, weighted by H_inv[3]
+	const float k3 = inv_o * inv_o * hv[3];              // dL_dopacity = G dL_dalpha = w / opacity, weighted by H_inv[3]
+	float hcx, ncy, hcz;                                  // (-conic.x / 2, -conic.y, -conic.z / 2)
 	if constexpr (REWRITE)
 	{
+		hcx = -0.5f * a0.z; ncy = -a0.w; hcz = -0.5f * a1.x;
 		sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
-		sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
+		sp[1] = make_float4(hcx, ncy, hcz, gsv[9] + gsv[10] + gsv[11]);
 	}
+	else
+	{
+		// the conic again (forward.cu:222-231), from the cov2D the Jacobian chain has just rebuilt -- not re-read from recB
+		const float ca = cov2d[0] + 0.3f, cb = cov2d[1], cc = cov2d[2] + 0.3f;
+		const float inv_det = __builtin_amdgcn_rcpf(ca * cc - cb * cb);
+		hcx = -0.5f * cc * inv_det; ncy = cb * inv_det; hcz = -0.5f * ca * inv_det;
+	}
+	// u' is a polynomial in d = mean - pixel: u'0 = a0 dx + b0 dy, u'1 = a1 dx + b1 dy, u'2..4 = dx^2, dx dy, dy^2, so the
+	// pair's factor u'^T Q u' is a bivariate polynomial with terms of degree 2, 3 and 4 only: 12 coefficients, which the walk
+	// evaluates by Horner's rule in 14 operations (26 for the quadratic form).  qf: Q' row-major upper triangle, (i, j) at
+	// 0 1 2 3 4 / 5 6 7 8 / 9 10 11 / 12 13 / 14.
+	const float pa0 = 2.0f * hcx, pb0 = ncy, pa1 = ncy, pb1 = 2.0f * hcz;
+	const float c20 = qf[0] * pa0 * pa0 + qf[1] * pa0 * pa1 + qf[5] * pa1 * pa1;
+	const float c11 = 2.0f * qf[0] * pa0 * pb0 + qf[1] * (pa0 * pb1 + pa1 * pb0) + 2.0f * qf[5] * pa1 * pb1;
+	const float c02 = qf[0] * pb0 * pb0 + qf[1] * pb0 * pb1 + qf[5] * pb1 * pb1;
+	const float c30 = qf[2] * pa0 + qf[6] * pa1;
+	const float c21 = qf[2] * pb0 + qf[3] * pa0 + qf[6] * pb1 + qf[7] * pa1;
+	const float c12 = qf[3] * pb0 + qf[4] * pa0 + qf[7] * pb1 + qf[8] * pa1;
+	const float c03 = qf[4] * pb0 + qf[8] * pb1;
+	const float c40 = qf[9], c31 = qf[10], c22 = qf[11] + qf[12], c13 = qf[13], c04 = qf[14];
 	float4* dq = recq + ((size_t)v * p.P + id) * 4;
-#pragma unroll
-	for (int k = 0; k < 4; k++) dq[k] = make_float4(qf[4 * k], qf[4 * k + 1], qf[4 * k + 2], qf[4 * k + 3]);
+	dq[0] = make_float4(c02, c03, c04, c11);
+	dq[1] = make_float4(c12, c13, c20, c21);
+	dq[2] = make_float4(c22, c30, c31, c40);
+	dq[3] = make_float4(k3, 0.f, 0.f, 0.f);
 }
 
 // Stand-alone form of phase C of k_preprocess_views, for the single-view front end (images beyond FR_MAX_LDS_TILES tiles,
@@ -2275,12 +2302,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_records(FrParams p, FrRec
 #define FR_ENT_F4 7                   // float4 per parked candidate record: 6 used + 1 pad -- a 28-dword stride spreads sixteen consecutive
                                      // candidates over all 64 LDS banks for ds_read_b128 (a 24-dword stride repeats after eight)
 typedef float fr_v4f __attribute__((ext_vector_type(4)));
-// One candidate's parked record as the walk reads it back (six ds_read_b128).
-struct FrWalkRec { fr_v4f a, b4, q0, q1, q2, q3; };     // {x, y, ext, log2 o} {-cx/2, -cy, -cz/2, cg} {Q'[15], k3}
+// One candidate's parked record as k_fisher_tile_v3h reads it back (six ds_read_b128).
+struct FrWalkRec { fr_v4f a, b4, q0, q1, q2, q3; };     // {x, y, ext, log2 o} {-cx/2, -cy, -cz/2, cg} {A'[15], 1/o^2}
+// ... and as k_fisher_tile_v3 does (five): {x, y, k3, log2 o} {-cx/2, -cy, -cz/2, cg} {c02 c03 c04 c11} {c12 c13 c20 c21} {c22 c30 c31 c40}
+#define FR_ENT3_F4 5                 // a 20-dword stride is conflict-free for ds_read_b128 like the 28-dword one (5 and 16 coprime)
+struct FrWalkRec3 { fr_v4f a, b4, q0, q1, q2; };
 // Everything about one (pixel, candidate) pair that does not depend on the pixel's running state.
 struct FrWalkGeom { bool ok; float a_un, alpha, om1, bi, cg, add; };
 
-__device__ __forceinline__ FrWalkGeom fr_walk_geom(const FrWalkRec& r, float pfx, float pfy)
+__device__ __forceinline__ FrWalkGeom fr_walk_geom(const FrWalkRec3& r, float pfx, float pfy)
 {
 #pragma clang fp contract(fast)
 	FrWalkGeom g;
@@ -2294,16 +2324,16 @@ __device__ __forceinline__ FrWalkGeom fr_walk_geom(const FrWalkRec& r, float pfx
 	g.om1 = 1.f - g.alpha;
 	g.bi = __builtin_amdgcn_rcpf(g.om1);
 	g.cg = r.b4.w;
-	const float u0 = r.b4.x * dx + (r.b4.x * dx + r.b4.y * dy);           // -(cx dx + cy dy)
-	const float u1 = 2.0f * (r.b4.z * dy) + r.b4.y * dx;                    // -(cz dy + cy dx)
-	const float u2 = dx * dx, u3 = dx * dy, u4 = dy * dy;
-	// u'^T Q u' over the upper triangle (off-diagonal entries pre-doubled by fr_fisher_record_one), row by row
-	const float t0 = r.q0.x * u0 + r.q0.y * u1 + r.q0.z * u2 + r.q0.w * u3 + r.q1.x * u4;
-	const float t1 = r.q1.y * u1 + r.q1.z * u2 + r.q1.w * u3 + r.q2.x * u4;
-	const float t2 = r.q2.y * u2 + r.q2.z * u3 + r.q2.w * u4;
-	const float t3 = r.q3.x * u3 + r.q3.y * u4;
-	const float t4 = r.q3.z * u4;
-	const float add = r.q3.w + u0 * t0 + u1 * t1 + u2 * t2 + u3 * t3 + u4 * t4;
+	// u'^T Q u' + k3 as the bivariate polynomial of fr_fisher_record_one (terms of degree 2..4 in dx, dy), Horner in dx
+	const float A0 = r.q0.x + dy * (r.q0.y + dy * r.q0.z);
+	const float A1 = r.q0.w + dy * (r.q1.x + dy * r.q1.y);
+	const float A2 = r.q1.z + dy * (r.q1.w + dy * r.q2.x);
+	const float A3 = r.q2.y + dy * r.q2.z;
+	const float dy2 = dy * dy;
+	const float in3 = A3 + dx * r.q2.w;
+	const float in2 = A2 + dx * in3;
+	const float in1 = dy * A1 + dx * in2;
+	const float add = (r.a.z + dy2 * A0) + dx * in1;
 	g.add = (g.a_un * g.a_un) * add;                                       // S_i = (opacity G)^2 (u'^T Q u' + k3)
 	return g;
 }
@@ -2330,20 +2360,24 @@ __device__ __forceinline__ bool fr_walk_update(const FrWalkGeom& g, bool live, f
 // One workgroup per (tile, view); the four waves own the four 16x4 strips and never synchronise until the final sum.
 //  stream   a wave reads the tile's sorted keys 64 at a time (one per lane), gathers recA and keeps the splats whose
 //           conservative alpha footprint meets its strip (one ballot); survivors are appended, in order, to a ring in LDS;
-//  chunk    64 queued candidates, one per lane: the lane gathers recB + recQ and parks the 96-byte record in LDS; it
+//  chunk    64 queued candidates, one per lane: the lane gathers recB + recQ and parks an 80-byte record in LDS (k3 in the
+//           place of the footprint extents, which only this step needs); it
 //           rasterises its footprint ellipse row by row into a 64-bit mask over the strip's pixels, and a 64x64 bit
 //           transpose across the wave hands every pixel-lane the mask of candidates that may touch it;
-//  walk     every pixel-lane walks its own set bits front to back: six ds_read_b128 of the candidate's record, the pair
+//  walk     every pixel-lane walks its own set bits front to back: five ds_read_b128 of the candidate's record, the pair
 //           test, the transmittance / colour prefix recurrences and the three sums.  A finished pixel clears its masks;
 //           a wave whose 64 pixels are finished leaves.
 // BW x BH = the 64 pixels of a wave inside the 16 x 16 tile: 16 x 4 strips (used), or 8 x 8 blocks (5 % slower on MI355X).
 template <int BW, int BH>
-__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5)))
+#ifndef FR_V3_WAVES
+#define FR_V3_WAVES 5
+#endif
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, FR_V3_WAVES)))
 void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
 {
 	static_assert(BW * BH == 64 && 16 % BW == 0, "a wave owns 64 pixels of the tile");
 	__shared__ uint32_t s_q[4][FR_QCAP];
-	__shared__ float4 s_ent[4][64][FR_ENT_F4];
+	__shared__ float4 s_ent[4][64][FR_ENT3_F4];
 	__shared__ float s_red[4];
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -2363,7 +2397,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	const float4* rec = (const float4*)(p.splat + vP);
 	const float4* rq = recq + vP * 4;
 	uint32_t* wq = s_q[wave];
-	float4 (*ent)[FR_ENT_F4] = s_ent[wave];
+	float4 (*ent)[FR_ENT3_F4] = s_ent[wave];
 	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];   // LDS byte address
 
 	const float strip_lo = (float)by0, strip_hi = strip_lo + (float)(BH - 1);      // the wave's rows
@@ -2421,8 +2455,10 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		{
 			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
 			const float4 a = rec[2 * (size_t)id], b4 = rec[2 * (size_t)id + 1];
-			const float4 q0 = rq[4 * (size_t)id], q1 = rq[4 * (size_t)id + 1], q2 = rq[4 * (size_t)id + 2], q3 = rq[4 * (size_t)id + 3];
-			ent[lane][0] = a; ent[lane][1] = b4; ent[lane][2] = q0; ent[lane][3] = q1; ent[lane][4] = q2; ent[lane][5] = q3;
+			const float4 q0 = rq[4 * (size_t)id], q1 = rq[4 * (size_t)id + 1], q2 = rq[4 * (size_t)id + 2];
+			const float k3 = ((const float*)(rq + 4 * (size_t)id + 3))[0];
+			ent[lane][0] = make_float4(a.x, a.y, k3, a.w);        // the footprint extents are only needed here, k3 takes their place
+			ent[lane][1] = b4; ent[lane][2] = q0; ent[lane][3] = q1; ent[lane][4] = q2;
 			const float ax = a.x, ay = a.y;
 			const uint32_t eb = __float_as_uint(a.z);
 			const float ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
@@ -2467,8 +2503,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 #ifdef FR_LOOPSTATS
 		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; dbg_t0 = t; }
 #endif
-		// ---- walk: every pixel-lane walks its own candidates front to back (the set bits of `mask`).  The candidate's 96-byte
-		// record comes back as six ds_read_b128 (hipcc splits plain float4 LDS loads into dword pairs here).
+		// ---- walk: every pixel-lane walks its own candidates front to back (the set bits of `mask`).  The candidate's 80-byte
+		// record comes back as five ds_read_b128 (hipcc splits plain float4 LDS loads into dword pairs here).
 		// The number of steps (set by the busiest lane of the chunk) times a per-step latency is what this loop costs; DESIGN.md
 		// section 4 lists what was tried on it without gain (two candidates per trip, prefetching the next record, two pixels per
 		// lane with packed arithmetic, per-row polynomials, arithmetic predicates in a wave-uniform loop, 4 / 5 / 6 waves per SIMD).
@@ -2476,13 +2512,13 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		{
 			const int j = __ffsll((long long)mask) - 1;
 			mask &= mask - 1ull;
-			FrWalkRec r;
+			FrWalkRec3 r;
 			{
-				const uint32_t addr = ent_lds + (uint32_t)j * (FR_ENT_F4 * 16);
-				asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
-				             "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
+				const uint32_t addr = ent_lds + (uint32_t)j * (FR_ENT3_F4 * 16);
+				asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+				             "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\t"
 				             "s_waitcnt lgkmcnt(0)"
-				             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2), "=&v"(r.q3) : "v"(addr) : "memory");
+				             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2) : "v"(addr) : "memory");
 			}
 #ifdef FR_LOOPSTATS
 			dbg_steps++; dbg_cs++;
@@ -3923,7 +3959,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.radii = o; o = fr_align(o + (size_t)V * nblk_v * (size_t)(FR_THREADS * fr_pick_G_views(P)) * sizeof(FrVisEntry));
 	L.vis_n = o; o = fr_align(o + (size_t)V * nblk_v * 4);
 	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
-	L.recq = o; o = fr_align(o + VP * 64);                // k_fisher_records: {Q'[15], k3} per (view, Gaussian), written where visible
+	L.recq = o; o = fr_align(o + VP * 64);                // k_fisher_records: 12 polynomial coefficients + k3 (or A'[15], 1/o^2) per (view, Gaussian), written where visible
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
 	L.blk_base = o; o = fr_align(o + (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4);

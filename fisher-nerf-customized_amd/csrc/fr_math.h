@@ -452,10 +452,11 @@ FR_HD void fr_cov3d_backward(fr_f3 scale, float mod, fr_f4 rot, const float* dco
 template <bool FAST = false>
 FR_HD void fr_mean_jacobian(fr_f3 mean, const float* cov3D, const float* view, const float* proj,
                             float focal_x, float focal_y, float tan_fovx, float tan_fovy,
-                            float A[3][5], float (*B)[3])
+                            float A[3][5], float (*B)[3], float* cov2d_out = nullptr)
 {
 	fr_cov2d c;
 	fr_cov2d_setup<FAST>(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c);
+	if (cov2d_out) { cov2d_out[0] = c.cov00; cov2d_out[1] = c.cov01; cov2d_out[2] = c.cov11; }   // before the +0.3 low-pass
 	float Mp[3][2];
 	fr_proj_jacobian<FAST>(mean, proj, Mp);
 	for (int k = 0; k < 3; k++) { A[k][0] = Mp[k][0]; A[k][1] = Mp[k][1]; }
