@@ -448,6 +448,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 
 // (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
 struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; };
+// floats per Gaussian of the packed static record (k_pack_static): {mean 3, cov3D 6, rgb 3, (scale 3, rot 4), H_inv C}
+template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
 template <int C, bool REWRITE, bool FORM_A = false>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
@@ -524,7 +526,26 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 			const int i = i0 + (int)(pr & 255u);
 			const int vv = (int)(pr >> 8);
 			const int v = v0 + vv;
-			const fr_f3 pw = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+			// mean, cov3D and colour of the Gaussian: three 16-byte loads of its packed static record when there is one (records
+			// modes), thirteen scattered dwords otherwise -- the same values either way
+			fr_f3 pw;
+			float c3[6];
+			float cg = 0.f;
+			if constexpr (RC != 0)
+			{
+				constexpr int PSB = FrPackSize<(RC < 0 ? -RC : RC)>::value;
+				const float4* pk = (const float4*)(ra.packed + (size_t)i * PSB);
+				const float4 t0 = pk[0], t1 = pk[1], t2 = pk[2];
+				pw = fr_f3{ t0.x, t0.y, t0.z };
+				c3[0] = t0.w; c3[1] = t1.x; c3[2] = t1.y; c3[3] = t1.z; c3[4] = t1.w; c3[5] = t2.x;
+				cg = t2.y + t2.z + t2.w;
+			}
+			else
+			{
+				pw = fr_f3{ p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+#pragma unroll
+				for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
+			}
 			float wm[12];
 			if (has_w2c)
 			{
@@ -532,9 +553,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 				for (int k = 0; k < 12; k++) wm[k] = s_wm[12 * vv + k];
 			}
 			const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
-			float c3[6];
-#pragma unroll
-			for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
 			const fr_splat s = fr_preprocess_one(po, c3, vm, pm, p.W, p.H, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.gx, p.gy);
 			if (s.radius > 0)
 			{
@@ -544,7 +562,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 				if constexpr (RC != 0)
 				{
 					// score-only mode: the scorer's {recA, recB} form straight away (see k_fisher_tile_v3)
-					const float cg = p.colors[3 * (size_t)i] + p.colors[3 * (size_t)i + 1] + p.colors[3 * (size_t)i + 2];
 					dst[0] = make_float4(s.px, s.py, __uint_as_float(ext), __builtin_amdgcn_logf(o));
 					dst[1] = make_float4(-0.5f * s.conx, -s.cony, -0.5f * s.conz, cg);
 				}
@@ -1553,7 +1570,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 // H_inv[C] } = 16 floats (64 B, one cache line) at C = 4, 32 floats at C = 11.  k_build_records then needs two gathers
 // per tile instance (this record and the 32-byte FrSplat) instead of six.  With per-view H_inv the weights are
 // gathered separately.
-template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
 
 template <int C>
 __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed)
