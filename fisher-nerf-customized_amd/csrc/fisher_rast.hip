@@ -3673,7 +3673,9 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	// The three sort tiers touch disjoint tile segments.  The 1024-thread tier has few, long-running workgroups (one per
 	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
 	FrSideStream& side = fr_side_stream();
-	const bool forked = fr_debug_mode() != 7 && side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;   // FR_DEBUG_MODE=7: every sort tier on the caller's stream (timing ablation)
+	// (a handful of views: the fork / join events cost more than the overlap gains -- one view 0.478 against 0.500 ms)
+	const bool want_fork = fr_debug_mode() != 7 && (!multi || p.V >= 8);   // FR_DEBUG_MODE=7: every sort tier on the caller's stream (timing ablation)
+	const bool forked = want_fork && side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
 	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
 	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
