@@ -2360,8 +2360,8 @@ __device__ __forceinline__ bool fr_walk_update(const FrWalkGeom& g, bool live, f
 {
 #pragma clang fp contract(fast)
 	const float test_T = T * g.om1;
-	const bool kill = live && (test_T < 0.0001f);
-	const bool con = live && !kill;
+	const bool con = live && !(test_T < 0.0001f);
+	const bool kill = live != con;                                           // one compare; the complement is a scalar xor of the two lane masks
 	const float S = con ? g.add : 0.f;
 	Xt = (con && T == 1.0f) ? g.cg : Xt;                                   // centre: the first contributor's colour
 	Cg = con ? Cg + g.cg * (g.alpha * T) : Cg;
@@ -2415,6 +2415,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	uint32_t* wq = s_q[wave];
 	float4 (*ent)[FR_ENT3_F4] = s_ent[wave];
 	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];   // LDS byte address
+	uint32_t ent_lds_v;                            // ... kept in a vector register: the walk's address is then one v_mad per step
+	asm volatile("v_mov_b32 %0, %1" : "=v"(ent_lds_v) : "s"(ent_lds));
 
 	const float strip_lo = (float)by0, strip_hi = strip_lo + (float)(BH - 1);      // the wave's rows
 	const float tile_x0 = (float)bx0, tile_x1 = tile_x0 + (float)(BW - 1);         // ... and columns
@@ -2530,7 +2532,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 			mask &= mask - 1ull;
 			FrWalkRec3 r;
 			{
-				const uint32_t addr = ent_lds + (uint32_t)j * (FR_ENT3_F4 * 16);
+				const uint32_t addr = ent_lds_v + (uint32_t)j * (FR_ENT3_F4 * 16);
 				asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
 				             "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\t"
 				             "s_waitcnt lgkmcnt(0)"
