@@ -1297,9 +1297,31 @@ __device__ __forceinline__ unsigned long long fr_transpose_round(unsigned long l
 	constexpr unsigned long long m = SFT == 32 ? 0x00000000FFFFFFFFull : SFT == 16 ? 0x0000FFFF0000FFFFull :
 	                                 SFT == 8 ? 0x00FF00FF00FF00FFull : SFT == 4 ? 0x0F0F0F0F0F0F0F0Full :
 	                                 SFT == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-	const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)x, SFT, 64);
-	const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), SFT, 64);
-	const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+	// the partner lane's row on the VALU (DPP inside a row of 16 lanes, gfx950's row / half swaps beyond) -- six dependent
+	// ds_bpermute round trips otherwise
+	unsigned long long other;
+	if constexpr (SFT == 1) other = fr_dpp64<0xB1>(x);                          // quad_perm [1,0,3,2]
+	else if constexpr (SFT == 2) other = fr_dpp64<0x4E>(x);                     // quad_perm [2,3,0,1]
+	else if constexpr (SFT == 4) other = fr_dpp64<0x141>(fr_dpp64<0x1B>(x));    // (i ^ 3) ^ 7 = i ^ 4
+	else if constexpr (SFT == 8) other = fr_dpp64<0x128>(x);                    // row_ror:8
+	else
+	{
+		const uint32_t l = (uint32_t)x, h = (uint32_t)(x >> 32);
+		unsigned long long a, b;                                                // a: the lower member's row on both lanes of a pair, b: the upper's
+		if constexpr (SFT == 16)
+		{
+			const auto tl = __builtin_amdgcn_permlane16_swap(l, l, false, false);
+			const auto th = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+			a = ((unsigned long long)th[0] << 32) | tl[0]; b = ((unsigned long long)th[1] << 32) | tl[1];
+		}
+		else
+		{
+			const auto tl = __builtin_amdgcn_permlane32_swap(l, l, false, false);
+			const auto th = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+			a = ((unsigned long long)th[0] << 32) | tl[0]; b = ((unsigned long long)th[1] << 32) | tl[1];
+		}
+		other = (lane & SFT) ? a : b;
+	}
 	return (lane & SFT) ? ((x & ~m) | ((other & ~m) >> SFT)) : ((x & m) | ((other & m) << SFT));
 }
 __device__ __forceinline__ unsigned long long fr_wave_transpose64(unsigned long long x, int lane)
@@ -2609,8 +2631,8 @@ __device__ __forceinline__ FrPairAlpha fr_pair_alpha(const fr_v4f& a, const fr_v
 __device__ __forceinline__ bool fr_prefix_update(const FrPairAlpha& g, float cg, float& T, double& Cg, bool& con)
 {
 	const float test_T = T * g.om1;
-	const bool kill = g.ok && (test_T < 0.0001f);
-	con = g.ok && !kill;
+	con = g.ok && !(test_T < 0.0001f);
+	const bool kill = g.ok != con;
 	const float term = cg * (g.alpha * T);
 	Cg = con ? Cg + (double)term : Cg;
 	T = con ? test_T : T;
