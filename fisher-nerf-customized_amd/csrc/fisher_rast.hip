@@ -3442,12 +3442,21 @@ static inline int fr_pick_G(long long P, long long V)
 // multi-view front end: 256*G Gaussians x VC views per workgroup
 static inline int fr_pick_G_views(long long P)
 {
-	long long gwant = P / ((long long)FR_THREADS * 256);     // ~256 workgroups along P at least
+	static int forced = -1;                                   // FR_GV=<n>: A/B runs
+	if (forced < 0) { const char* e = getenv("FR_GV"); forced = e ? atoi(e) : 0; }
+	if (forced > 0) return forced > 8 ? 8 : forced;
+	// ~640 workgroups along P (measured on MI355X, 500k Gaussians x 64 views, ms per step: G = 1: 2.24, 2: 2.20, 3: 2.17-2.20,
+	// 4: 2.19-2.22, 7: 2.26, 10: 2.37 -- the kernel wants two to three rounds of small workgroups, not one of large ones)
+	long long gwant = P / ((long long)FR_THREADS * 640);
 	return (int)(gwant < 1 ? 1 : (gwant > 8 ? 8 : gwant));
 }
 static inline int fr_pick_VC(long long T)
 {
+	static int forced = -1;                                   // FR_VC=<n>: A/B runs
+	if (forced < 0) { const char* e = getenv("FR_VC"); forced = e ? atoi(e) : 0; }
 	long long vc = 8192 / (T < 1 ? 1 : T);
+	if (forced > 0) return (int)(forced > vc ? (vc < 1 ? 1 : vc) : forced);
+	if (vc > 4) vc = 4;                                       // 4 views per workgroup: 2.16 ms per step against 2.20 for 8 and 2.19 for 2
 	return (int)(vc < 1 ? 1 : (vc > 8 ? 8 : vc));
 }
 static inline long long fr_preprocess_blocks(long long P, long long V)
