@@ -2496,10 +2496,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[2 * (size_t)id1]; }
 	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
 	uint32_t base = 0;
-	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
-	while (!all_done)
-	{
-		// ---- stream: fill the queue up to one chunk
+	// ---- stream: fill the queue up to one chunk
+	auto stream_fill = [&]() {
 #ifdef FR_LOOPSTATS
 		dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -2522,23 +2520,42 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 #ifdef FR_LOOPSTATS
 		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_ts += t - dbg_t0; dbg_t0 = t; }
 #endif
-		if (qn == 0) break;
-		// ---- chunk: up to 64 candidates, one per lane
-		const uint32_t m = qn < 64u ? qn : 64u;
-#ifdef FR_LOOPSTATS
-		dbg_chunks++; dbg_cand += (int)m;
-#endif
+	};
+	// ---- the next chunk's records, gathered into registers one chunk ahead (the gathers then fly during the walk of the
+	// current chunk instead of in front of it); up to 64 candidates, one per lane
+	float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pq0 = pa, pq1 = pa, pq2 = pa;
+	float pk3 = 0.f;
+	uint32_t pm = 0;                                 // candidates in the gathered chunk, wave-uniform
+	auto gather_next = [&]() {
+		pm = qn < 64u ? qn : 64u;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		if ((uint32_t)lane < pm)
+		{
+			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
+			pa = rec[2 * (size_t)id]; pb = rec[2 * (size_t)id + 1];
+			pq0 = rq[4 * (size_t)id]; pq1 = rq[4 * (size_t)id + 1]; pq2 = rq[4 * (size_t)id + 2];
+			pk3 = ((const float*)(rq + 4 * (size_t)id + 3))[0];
+		}
+		qh = (qh + pm) & (FR_QCAP - 1); qn -= pm;
+	};
+	stream_fill();
+	gather_next();
+	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	while (!all_done && pm != 0u)
+	{
+		// ---- chunk: park the gathered records in LDS, rasterise the footprints
+		const uint32_t m = pm;
+#ifdef FR_LOOPSTATS
+		dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+		dbg_chunks++; dbg_cand += (int)m;
+#endif
 		unsigned long long emask = 0ull;
 		if ((uint32_t)lane < m)
 		{
-			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
-			const float4 a = rec[2 * (size_t)id], b4 = rec[2 * (size_t)id + 1];
-			const float4 q0 = rq[4 * (size_t)id], q1 = rq[4 * (size_t)id + 1], q2 = rq[4 * (size_t)id + 2];
-			const float k3 = ((const float*)(rq + 4 * (size_t)id + 3))[0];
-			ent[lane][0] = make_float4(a.x, a.y, k3, a.w);        // the footprint extents are only needed here, k3 takes their place
-			ent[lane][1] = b4; ent[lane][2] = q0; ent[lane][3] = q1; ent[lane][4] = q2;
+			const float4 a = pa, b4 = pb;
+			ent[lane][0] = make_float4(a.x, a.y, pk3, a.w);       // the footprint extents are only needed here, k3 takes their place
+			ent[lane][1] = b4; ent[lane][2] = pq0; ent[lane][3] = pq1; ent[lane][4] = pq2;
 			const float ax = a.x, ay = a.y;
 			const uint32_t eb = __float_as_uint(a.z);
 			const float ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
@@ -2575,19 +2592,23 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 				}
 			}
 		}
-		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
 		unsigned long long mask = fr_wave_transpose64(emask, lane);
 		if (done) mask = 0ull;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 #ifdef FR_LOOPSTATS
-		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; dbg_t0 = t; }
+		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; }
+#endif
+		// ---- refill the queue and start the next chunk's gathers before walking this one
+		stream_fill();
+		gather_next();
+#ifdef FR_LOOPSTATS
+		dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
 		// ---- walk: every pixel-lane walks its own candidates front to back (the set bits of `mask`).  The candidate's 80-byte
 		// record comes back as five ds_read_b128 (hipcc splits plain float4 LDS loads into dword pairs here).
-		// The number of steps (set by the busiest lane of the chunk) times a per-step latency is what this loop costs; DESIGN.md
-		// section 4 lists what was tried on it without gain (two candidates per trip, prefetching the next record, two pixels per
-		// lane with packed arithmetic, per-row polynomials, arithmetic predicates in a wave-uniform loop, 4 / 5 / 6 waves per SIMD).
+		// The number of steps (set by the busiest lane of the chunk) times a per-step cost is what this loop costs; DESIGN.md
+		// section 4 lists what was tried on it.
 		while (mask != 0ull)
 		{
 			const int j = __ffsll((long long)mask) - 1;
