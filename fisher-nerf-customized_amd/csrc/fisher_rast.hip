@@ -2592,18 +2592,21 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 				}
 			}
 		}
+#ifdef FR_LOOPSTATS
+		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; }
+#endif
+		// ---- refill the queue and start the next chunk's gathers before the transpose and the walk of this one
+		stream_fill();
+		gather_next();
+#ifdef FR_LOOPSTATS
+		dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
 		unsigned long long mask = fr_wave_transpose64(emask, lane);
 		if (done) mask = 0ull;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 #ifdef FR_LOOPSTATS
-		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; }
-#endif
-		// ---- refill the queue and start the next chunk's gathers before walking this one
-		stream_fill();
-		gather_next();
-#ifdef FR_LOOPSTATS
-		dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; dbg_t0 = t; }
 #endif
 		// ---- walk: every pixel-lane walks its own candidates front to back (the set bits of `mask`).  The candidate's 80-byte
 		// record comes back as five ds_read_b128 (hipcc splits plain float4 LDS loads into dword pairs here).
