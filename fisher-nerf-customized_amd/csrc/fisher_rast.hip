@@ -4052,7 +4052,12 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	return fr_check_launch("k_backward_finish");
 }
 
-// FR_DEBUG_MODE (timing ablations / loop statistics only), read once per process
+// FR_DEBUG_MODE (timing ablations / loop statistics only), read once per process:
+//   1  k_fisher_tile_v2 stops after its first pass            6  the LDS-resident sort network of round 1
+//   7  every sort tier on the caller's stream (no fork)       8  8 x 8 pixel blocks per wave in k_fisher_tile_v3
+//   9  the second-generation two-pass kernels instead of k_fisher_tile_v3 / _v3h
+//   2-7, 10-12 in a -DFR_LOOPSTATS build: loop-trip counters and s_memtime shares (tools/loopstats.py)
+// FR_GV / FR_VC (read once as well): Gaussians per thread / views per workgroup of k_preprocess_views.
 static int fr_debug_mode()
 {
 	static const int mode = [] { const char* dm = getenv("FR_DEBUG_MODE"); return dm ? atoi(dm) : 0; }();
