@@ -487,7 +487,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 }
 
 // (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
-struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; };
+struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; const float* cov_trace; };   // cov_trace [P] or null: trace of cov3D (k_pack_static), for the early frustum test
 // floats per Gaussian of the packed static record (k_pack_static): {mean 3, cov3D 6, rgb 3, (scale 3, rot 4), H_inv C}
 template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
 template <int C, bool REWRITE, bool FORM_A = false>
@@ -542,11 +542,42 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 			const bool live = i < p.P;
 			fr_f3 pw = { 0.f, 0.f, 0.f };
 			if (live) pw = fr_f3{ p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+			// Early frustum test (records modes): about half of the splats in front of the camera end with an empty tile rectangle
+			// (forward.cu:233-236) -- after the whole cov2D chain.  radius = ceil(3 sqrt(lambda1)) and
+			//   lambda1 <= lambda_max(cov2D) + 0.3 + sqrt(0.1),   lambda_max(cov2D) <= |J|_F^2 lambda_max(cov3D),
+			//   |J|_F^2 = (fx^2 (1 + jx^2) + fy^2 (1 + jy^2)) / z^2,  jx = min(|x / z|, 1.3 tan_fovx) (the clamp of forward.cu:80-84),
+			// times |W|_2^2 of the view matrix's 3 x 3, and lambda_max(cov3D) <= trace(cov3D) (k_pack_static), so a centre further than
+			// that bound (+ 2 % and 2 px for rounding) outside the tile grid cannot touch it.  NaNs keep the pair.
+			const bool early = RC != 0 && ra.cov_trace != nullptr;
+			float tr = 0.f;
+			if (early && live) tr = ra.cov_trace[i];
+			const float lx = 1.3f * p.tanfovx, ly = 1.3f * p.tanfovy;
+			// |W|_2^2 <= |W|_1 |W|_inf for the 3 x 3 of the view matrix (1 for the identity the scorer's camera has)
+			float wn;
+			{
+				const float c0 = fabsf(vm[0]) + fabsf(vm[1]) + fabsf(vm[2]), c1 = fabsf(vm[4]) + fabsf(vm[5]) + fabsf(vm[6]), c2 = fabsf(vm[8]) + fabsf(vm[9]) + fabsf(vm[10]);
+				const float r0 = fabsf(vm[0]) + fabsf(vm[4]) + fabsf(vm[8]), r1 = fabsf(vm[1]) + fabsf(vm[5]) + fabsf(vm[9]), r2 = fabsf(vm[2]) + fabsf(vm[6]) + fabsf(vm[10]);
+				wn = fmaxf(c0, fmaxf(c1, c2)) * fmaxf(r0, fmaxf(r1, r2));
+			}
+			const float fx2 = 1.02f * wn * p.focal_x * p.focal_x, fy2 = 1.02f * wn * p.focal_y * p.focal_y;
+			const float xmax = (float)(p.gx * FR_BLOCK_X + FR_BLOCK_X), ymax = (float)(p.gy * FR_BLOCK_Y + FR_BLOCK_Y);
 			for (int vv = 0; vv < nv; vv++)
 			{
 				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, s_wm + 12 * vv) : pw;
 				const fr_f3 p_view = fr_xform4x3(po, vm);
-				const bool keep = live && !(p_view.z <= 0.001f);
+				bool keep = live && !(p_view.z <= 0.001f);
+				if (early)
+				{
+					const fr_f4 ph = fr_xform4x4(po, pm);
+					const float p_w = 1.0f / (ph.w + 0.0000001f);
+					const float px = ((ph.x * p_w + 1.0f) * (float)p.W - 1.0f) * 0.5f, py = ((ph.y * p_w + 1.0f) * (float)p.H - 1.0f) * 0.5f;   // ndc2pix in float: the slack covers it
+					const float iz = 1.0f / p_view.z;
+					const float jx = fminf(fabsf(p_view.x * iz) * 1.001f, lx), jy = fminf(fabsf(p_view.y * iz) * 1.001f, ly);
+					const float kc = fx2 * (1.0f + jx * jx) + fy2 * (1.0f + jy * jy);
+					const float rb = 3.0f * sqrtf(kc * tr * (iz * iz) + 0.7f) + 2.0f;
+					const bool outside = (px + rb < 0.f) || (px - rb > xmax) || (py + rb < 0.f) || (py - rb > ymax);
+					keep = keep && !outside;
+				}
 				const unsigned long long m = __ballot(keep);
 				if (m)
 				{
@@ -1634,7 +1665,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 // gathered separately.
 
 template <int C>
-__global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed)
+__global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed,
+                                                            float* __restrict__ cov_trace)
 {
 	constexpr int PS = FrPackSize<C>::value;
 	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
@@ -1646,6 +1678,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 	for (int k = 0; k < 3; k++) b[k] = p.means3D[3 * (size_t)i + k];
 #pragma unroll
 	for (int k = 0; k < 6; k++) b[3 + k] = p.cov3D[6 * (size_t)i + k];
+	// xx + yy + zz of the symmetric 3 x 3: an upper bound of its largest eigenvalue (the tighter (mod * largest scale)^2 only
+	// holds for unit quaternions, which forward.cu:120-151 does not require)
+	if (cov_trace) cov_trace[i] = b[3] + b[6] + b[8];
 #pragma unroll
 	for (int k = 0; k < 3; k++) b[9 + k] = p.colors[3 * (size_t)i + k];
 	int o = 12;
@@ -3689,7 +3724,7 @@ static FrSideStream& fr_side_stream(int which = 0)
 // Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
 // k_preprocess_views; with the single-view front end, k_fisher_records after k_scatter_keys, beside the sorts, on the second side stream).
 struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; };     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
-template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed);
+template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed, float* __restrict__ cov_trace);
 template <int C, bool LIST, bool FORM_A> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
 
 static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, const FrScorerPlan* plan = nullptr)
@@ -3720,8 +3755,8 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	{
 		const float* shared_hinv = plan->ra.hinv_stride ? nullptr : plan->ra.H_inv;
 		dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
-		if (plan->columns == 4) hipLaunchKernelGGL((k_pack_static<4>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed);
-		else hipLaunchKernelGGL((k_pack_static<11>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed);
+		if (plan->columns == 4) hipLaunchKernelGGL((k_pack_static<4>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float*)plan->ra.cov_trace);
+		else hipLaunchKernelGGL((k_pack_static<11>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float*)plan->ra.cov_trace);
 		if ((rc = fr_check_launch("k_pack_static"))) return rc;
 	}
 	FrSideStream* side2 = nullptr;
@@ -3729,7 +3764,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	{
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC) * 4;
-		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr };
+		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr };
 		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
@@ -3931,7 +3966,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		uint8_t* fallback = (uint8_t*)p.tile_fill;
 		FrParams pp = p;
 		pp.colors = g->colors_precomp;
-		hipLaunchKernelGGL((k_pack_static<25>), dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, pp, (const float*)nullptr, packed);
+		hipLaunchKernelGGL((k_pack_static<25>), dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, pp, (const float*)nullptr, packed, (float*)nullptr);
 		FrFisherArgs f;
 		memset(&f, 0, sizeof(f));
 		f.dL_img = dL_dout_color; f.dL_stride = 0;
@@ -4065,7 +4100,7 @@ static int fr_debug_mode()
 }
 
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, recq, packed, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, packed, cov_trace, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
@@ -4081,6 +4116,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
 	L.recq = o; o = fr_align(o + VP * 64);                // k_fisher_records: 12 polynomial coefficients + k3 (or A'[15], 1/o^2) per (view, Gaussian), written where visible
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
+	L.cov_trace = o; o = fr_align(o + (size_t)P * 4);
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
 	L.blk_base = o; o = fr_align(o + (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4);
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
@@ -4161,7 +4197,7 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t
 	const bool per_view = hi && f.hinv_stride != 0;
 	// wave-private passes over the sorted keys; tiles whose lists do not fit the LDS index are flagged ...
 	f.only_flagged = nullptr;
-	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed);
+	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed, (float*)nullptr);
 	// measurement hook: events around the dominant kernel only, on the stream it runs on
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_prof_on)
@@ -4247,6 +4283,9 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	plan.columns = fc->columns;
 	plan.ra.H_inv = fc->H_inv; plan.ra.hinv_stride = fc->H_inv_view_stride;
 	plan.ra.packed = (const float*)(ws + L.packed); plan.ra.recq = (float4*)(ws + L.recq);
+	// the early frustum test needs a positive semi-definite cov3D: the one k_cov3d builds, not a caller's precomputed one;
+	// FR_DEBUG_MODE=15 switches it off (A/B runs)
+	plan.ra.cov_trace = (g->cov3D_precomp || f.debug_mode == 15) ? nullptr : (const float*)(ws + L.cov_trace);
 	if ((rc = fr_bin_pipeline(p, g, s, (v3 || v3h) ? &plan : nullptr))) return rc;
 
 	if (v3) fr_launch_fisher_v3(p, f, plan.ra.recq, s);

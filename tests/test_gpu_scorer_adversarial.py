@@ -76,9 +76,32 @@ def threshold_scene(oracle, W=96, H=96, seed=7):
     return W, H, sc, np.eye(4, dtype=np.float32)
 
 
+def border_scene(W=112, H=80, seed=11):
+    """Splats in a band around the frustum's edges, with strongly anisotropic scales and quaternions that are NOT unit
+    (forward.cu:120-151 does not normalise them, so cov3D is scaled by |q|^4): whether such a splat reaches a tile is
+    decided by its radius alone.  This is what the early frustum test of k_preprocess_views has to get right -- it may only
+    drop a splat the reference drops (empty tile rectangle, forward.cu:233-236); vis_count and the scores would show it."""
+    rng = np.random.default_rng(seed)
+    P = 3000
+    z = rng.uniform(0.6, 5.0, P)
+    band = rng.uniform(0.7, 1.9, P) * rng.choice([-1.0, 1.0], P)          # tan of the angle off the axis: the image edge is at 1
+    free = rng.uniform(-1.6, 1.6, P)
+    side = rng.random(P) < 0.5
+    xz, yz = np.where(side, band, free), np.where(side, free, band)
+    means = np.stack([xz * z, yz * z, z], 1).astype(np.float32)
+    scales = np.exp(rng.normal(np.log(0.08), 1.0, (P, 3))).clip(0.004, 0.6).astype(np.float32)
+    rot = rng.normal(size=(P, 4))
+    rot *= (rng.uniform(0.5, 1.6, P) / np.linalg.norm(rot, axis=1))[:, None]
+    sc = dict(means3D=means, scales=scales, rotations=rot.astype(np.float32),
+              opacities=rng.uniform(0.05, 0.9, P).astype(np.float32), colors=rng.uniform(0, 1, (P, 3)).astype(np.float32))
+    return W, H, sc, np.eye(4, dtype=np.float32)
+
+
 def _family(case, oracle):
     if case == "thresholds":
         return threshold_scene(oracle)
+    if case == "border":
+        return border_scene()
     return _scene(case)
 
 
@@ -106,7 +129,7 @@ def family(gpu, oracle):
 
 
 @pytest.mark.parametrize("columns", [4, 11])
-@pytest.mark.parametrize("case", CASES + ["thresholds"])
+@pytest.mark.parametrize("case", CASES + ["thresholds", "border"])
 def test_scorer_modes_on_adversarial_families(family, gpu, case, columns):
     f = family(case)
     P, V, C = f["P"], len(f["w2cs"]), columns
@@ -129,29 +152,40 @@ def test_scorer_modes_on_adversarial_families(family, gpu, case, columns):
         # `general`, Gaussian 15762: 1.09e-4), so their entries are held to 1e-3; everything else to 1e-4.
         z = f["z_cam"][v]
         near = (z > 0) & (z < 0.2)
+        if case == "border":                # aspect ratios up to 150 and |q|^4 up to 6.5: the cov2D chain is as ill-conditioned there
+            near = np.ones_like(near)
         got = cur[v].cpu().numpy()
         assert_close(got[~near], cur_o[v][~near], 1e-4, f"{case} cur_H[{v}]", atol_frac=1e-7)
         if near.any():
-            assert_close(got[near], cur_o[v][near], 1e-3, f"{case} cur_H[{v}] near-plane", atol_frac=1e-7)
+            # (`border` is about WHICH splats are listed -- vis_count above, the scores below; its needle-shaped splats are held
+            # to 1e-3 with a floor of 1e-5 of the largest entry)
+            assert_close(got[near], cur_o[v][near], 1e-3, f"{case} cur_H[{v}] near-plane", atol_frac=1e-5 if case == "border" else 1e-7)
     Ht = torch.zeros((P, C), device=gpu)
     sc.run(w2c[1:], out_H=Ht)
     near_any = np.any([(z > 0) & (z < 0.2) for z in f["z_cam"][1:]], axis=0)
+    if case == "border":
+        near_any = np.ones_like(near_any)
     assert_close(Ht.cpu().numpy()[~near_any], H_train_o[~near_any], 1e-4, f"{case} H_train", atol_frac=1e-7)
-    assert_close(Ht.cpu().numpy()[near_any], H_train_o[near_any], 1e-3, f"{case} H_train near-plane", atol_frac=1e-7)
+    assert_close(Ht.cpu().numpy()[near_any], H_train_o[near_any], 1e-3, f"{case} H_train near-plane", atol_frac=1e-5 if case == "border" else 1e-7)
 
+    # `border`: needle-shaped splats (aspect ratios up to 150, cov3D scaled by |q|^4) make the conic's determinant a difference
+    # of nearly equal products; the two kernel generations, which evaluate the same chain with different instruction sequences,
+    # sit 1.6e-4 and 4.9e-4 from the oracle there (and agree with each other no better), so that family is held to 1e-3 --
+    # what it is for is the exact set of listed splats (vis_count), with and without the early frustum test.
+    stol = 1e-3 if case == "border" else 1e-4
     # score-only (the single-pass kernel), H_inv shared by the views
     H_inv = torch.from_numpy(H_inv_o).to(gpu)
     s = sc.run(w2c, H_inv=H_inv)
     assert np.array_equal(s["vis_count"].cpu().numpy(), vis_o)
-    assert rel_err(s["scores"].cpu().numpy(), want) < 1e-4, (case, s["scores"].cpu().numpy(), want)
+    assert rel_err(s["scores"].cpu().numpy(), want) < stol, (case, s["scores"].cpu().numpy(), want)
 
     # per-view H_inv (the path evaluator's mode)
     g = torch.Generator().manual_seed(5)
     Hv = (torch.rand((V, P, C), generator=g) * 3.0 + 0.05)
     want_pv = (cur_o.astype(np.float64) * Hv.numpy().astype(np.float64)).sum(axis=(1, 2))
     s_pv = sc.run(w2c, H_inv=Hv.to(gpu), H_inv_per_view=True)
-    assert rel_err(s_pv["scores"].cpu().numpy(), want_pv) < 1e-4, (case, s_pv["scores"].cpu().numpy(), want_pv)
+    assert rel_err(s_pv["scores"].cpu().numpy(), want_pv) < stol, (case, s_pv["scores"].cpu().numpy(), want_pv)
 
     # scores and materialised cur_H of the SAME launch sequence agree (gaussian.py:1367)
     s2 = (cur.double() * H_inv.double()[None]).sum(dim=(1, 2)).cpu().numpy()
-    assert rel_err(s["scores"].cpu().numpy(), s2) < 1e-4
+    assert rel_err(s["scores"].cpu().numpy(), s2) < stol
