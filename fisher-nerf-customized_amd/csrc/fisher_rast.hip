@@ -1677,7 +1677,19 @@ __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const fl
 #pragma unroll
 	for (int k = 0; k < 3; k++) b[k] = p.means3D[3 * (size_t)i + k];
 #pragma unroll
-	for (int k = 0; k < 6; k++) b[3 + k] = p.cov3D[6 * (size_t)i + k];
+	for (int k = 0; k < 6; k++) b[3 + k] = 0.f;
+	if (p.cov3D)
+	{
+#pragma unroll
+		for (int k = 0; k < 6; k++) b[3 + k] = p.cov3D[6 * (size_t)i + k];
+	}
+	else
+	{
+		// (fr_bin_pipeline leaves cov3D null when this kernel is its only reader: k_cov3d's arithmetic, forward.cu:118-152)
+		const fr_f3 sc = { p.scales[3 * (size_t)i], p.scales[3 * (size_t)i + 1], p.scales[3 * (size_t)i + 2] };
+		const fr_f4 q = { p.rots[4 * (size_t)i], p.rots[4 * (size_t)i + 1], p.rots[4 * (size_t)i + 2], p.rots[4 * (size_t)i + 3] };
+		fr_cov3d(sc, p.mod, q, &b[3]);
+	}
 	// xx + yy + zz of the symmetric 3 x 3: an upper bound of its largest eigenvalue (the tighter (mod * largest scale)^2 only
 	// holds for unit quaternions, which forward.cu:120-151 does not require)
 	if (cov_trace) cov_trace[i] = b[3] + b[6] + b[8];
@@ -3738,14 +3750,15 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		if (p.num_rendered && p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES) z.add(p.num_rendered, (size_t)p.V * 4);   // counted by k_preprocess_views
 		z.launch(s);
 	}
+	const bool multi = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;
 	if (g->cov3D_precomp) p.cov3D = g->cov3D_precomp;
+	else if (plan && multi) p.cov3D = nullptr;       // records mode of the multi-view front end: k_pack_static builds cov3D itself, nothing else reads it
 	else
 	{
 		hipLaunchKernelGGL(k_cov3d, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, s, P, g->scales, p.mod, g->rotations, p.cov3D_out);
 		if ((rc = fr_check_launch("k_cov3d"))) return rc;
 		p.cov3D = p.cov3D_out;
 	}
-	const bool multi = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;
 	p.G = multi ? fr_pick_G_views(P) : fr_pick_G(P, p.V);
 	p.VC = fr_pick_VC(p.T);
 	const int per_block = FR_THREADS * p.G;
