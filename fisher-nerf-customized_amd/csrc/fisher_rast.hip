@@ -2975,8 +2975,10 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 }
 
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
-                                                              const int* __restrict__ status, float* __restrict__ out_scores)
+                                                              const int* __restrict__ status, float* __restrict__ out_scores,
+                                                              int* __restrict__ status_out)
 {
+	if (blockIdx.x == 0 && threadIdx.x < 4) status_out[threadIdx.x] = status[threadIdx.x];   // the caller's copy of {total, overflow, max, 0}
 	if (status[1]) return;
 	__shared__ double s_part[FR_THREADS];
 	const int v = blockIdx.x, tid = threadIdx.x;
@@ -4309,10 +4311,10 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
 	if (fc->out_scores)
 	{
-		hipLaunchKernelGGL(k_reduce_scores, dim3(V), dim3(FR_THREADS), 0, s, f.tile_scores, p.T, p.status, fc->out_scores);
+		hipLaunchKernelGGL(k_reduce_scores, dim3(V), dim3(FR_THREADS), 0, s, f.tile_scores, p.T, p.status, fc->out_scores, status);
 		if ((rc = fr_check_launch("k_reduce_scores"))) return rc;
 	}
-	(void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
+	else (void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
 	return FR_OK;
 }
 
