@@ -2792,6 +2792,151 @@ __device__ __forceinline__ unsigned long long fr_footprint_mask(const float4& a,
 	return emask;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward compositing with the scorer's walk (k_fisher_tile_v3): the wave streams the tile's keys, keeps the splats whose
+// alpha footprint box meets its strip in an LDS ring, and then takes 64 candidates at a time -- one per lane: the lane parks
+// the candidate's record in LDS and rasterises its footprint ellipse into a 64-bit mask over the strip's pixels; a 64 x 64 bit
+// transpose hands every pixel-lane the mask of candidates that may touch it, and the lane walks ITS set bits front to back.
+// k_render_forward evaluates every surviving candidate on all 64 lanes (wave-uniform loop, v_readlane broadcasts): about three
+// times the steps.  The arithmetic of a (pixel, splat) pair and the order of the pairs of a pixel are those of
+// k_render_forward, so colour, depth, final_T and n_contrib stay bit-identical to the oracle's.
+template <int NCH>
+__global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, const float* __restrict__ feat, int feat_view_stride,
+                                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                                    float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                                    const float* __restrict__ feat2, float* __restrict__ out_color2)
+{
+	constexpr int EF4 = NCH == 6 ? 5 : 3;        // float4 per parked record (4 would repeat the LDS banks after four records)
+	__shared__ uint2 s_q[4][FR_QCAP];            // ring of {index, position in the tile's list}
+	__shared__ float4 s_ent[4][64][EF4];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int v = blockIdx.y;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const size_t vP = (size_t)v * p.P;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* splat = (const float4*)(p.splat + vP);
+	const float* fv = feat + (size_t)v * feat_view_stride;
+	uint2* wq = s_q[wave];
+	float4 (*ent)[EF4] = s_ent[wave];
+
+	float T = 1.0f;
+	uint32_t last_contributor = 0;
+	float C[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) C[c] = 0.f;
+	float D = 15.0f;
+	bool done = !inside;
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+
+	uint32_t qh = 0, qn = 0;
+	uint32_t id1 = 0, id2 = 0;
+	float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = e1;      // {x, y, ., .} and {., ., ., ext} of the keys at `base`
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; x1 = splat[2 * (size_t)id1]; e1 = splat[2 * (size_t)id1 + 1]; }
+	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
+	uint32_t base = 0;
+	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	while (!all_done)
+	{
+		// ---- stream: fill the ring up to one chunk
+		while (qn < 64u && base < n)
+		{
+			const uint32_t idc = id1; const float4 xc = x1, ec = e1;
+			id1 = id2;
+			if (base + 64 + lane < n) { x1 = splat[2 * (size_t)id2]; e1 = splat[2 * (size_t)id2 + 1]; }
+			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
+			const uint32_t eb = __float_as_uint(ec.w);
+			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			const bool ov = (base + lane < n) && hx >= 0.f && (xc.y + hy >= strip_lo) && (xc.y - hy <= strip_hi)
+			                && (xc.x + hx >= tile_x0) && (xc.x - hx <= tile_x1);
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = make_uint2(idc, base + (uint32_t)lane);
+			qn += (uint32_t)__popcll(om);
+			base += 64;
+		}
+		if (qn == 0) break;
+		// ---- chunk: up to 64 candidates, one per lane
+		const uint32_t m = qn < 64u ? qn : 64u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		unsigned long long emask = 0ull;
+		if ((uint32_t)lane < m)
+		{
+			const uint2 qe = wq[(qh + lane) & (FR_QCAP - 1)];
+			const uint32_t id = qe.x;
+			const float4 q0 = splat[2 * (size_t)id], q1 = splat[2 * (size_t)id + 1];   // {x, y, conx, cony} {conz, opacity, depth, ext}
+			ent[lane][0] = q0;
+			ent[lane][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), q1.z);
+			ent[lane][2] = make_float4(fv[3 * (size_t)id], fv[3 * (size_t)id + 1], fv[3 * (size_t)id + 2], __uint_as_float(qe.y));
+			if constexpr (NCH == 6) ent[lane][3] = make_float4(feat2[3 * (size_t)id], feat2[3 * (size_t)id + 1], feat2[3 * (size_t)id + 2], 0.f);
+			// the scorer's footprint rasteriser wants {x, y, ext, log2 opacity} {-conx / 2, -cony, -conz / 2, .}
+			const float4 a = make_float4(q0.x, q0.y, q1.w, __builtin_amdgcn_logf(q1.y));
+			const float4 b4 = make_float4(-0.5f * q0.z, -q0.w, -0.5f * q1.x, 0.f);
+			emask = fr_footprint_mask<16, 4>(a, b4, strip_lo, tile_x0);
+		}
+		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (done) mask = 0ull;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- walk
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
+			const float dx = r0.x - pfx, dy = r0.y - pfy;
+			const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+			// forward.cu:338-357; NaN falls through both tests as it does there
+			if (power > 0.0f || power < r1.z) continue;
+			const float G = fr_expf(power);
+			const float alpha = fminf(0.99f, r1.y * G);
+			if (alpha < 1.0f / 255.0f) continue;
+			const float test_T = T * (1 - alpha);
+			if (test_T < 0.0001f) { done = true; mask = 0ull; continue; }
+			C[0] = C[0] + r2.x * alpha * T; C[1] = C[1] + r2.y * alpha * T; C[2] = C[2] + r2.z * alpha * T;
+			if constexpr (NCH == 6)
+			{
+				const float4 r3 = ent[j][3];
+				C[3] = C[3] + r3.x * alpha * T; C[4] = C[4] + r3.y * alpha * T; C[5] = C[5] + r3.z * alpha * T;
+			}
+			D = (T > 0.5f && test_T < 0.5f) ? r1.w : D;
+			T = test_T;
+			last_contributor = __float_as_uint(r2.w) + 1u;
+		}
+		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	}
+	if (inside)
+	{
+		const size_t HW = (size_t)p.H * p.W;
+		const size_t pix = (size_t)p.W * pxy + pxx;
+		final_T[v * HW + pix] = T;
+		n_contrib[v * HW + pix] = last_contributor;
+		if (out_color)
+		{
+			out_color[(v * 3 + 0) * HW + pix] = C[0] + T * p.bg[0];
+			out_color[(v * 3 + 1) * HW + pix] = C[1] + T * p.bg[1];
+			out_color[(v * 3 + 2) * HW + pix] = C[2] + T * p.bg[2];
+		}
+		if constexpr (NCH == 6)
+		{
+			out_color2[(v * 3 + 0) * HW + pix] = C[3] + T * p.bg[0];
+			out_color2[(v * 3 + 1) * HW + pix] = C[4] + T * p.bg[1];
+			out_color2[(v * 3 + 2) * HW + pix] = C[5] + T * p.bg[2];
+		}
+		if (out_depth) out_depth[v * HW + pix] = D;
+	}
+}
+
 // The stream / chunk skeleton of k_fisher_tile_v3 for one pass of one wave; NQ = float4 of recq parked per candidate.
 // body(m, id, emask) runs once per chunk of m <= 64 candidates: lane l < m holds candidate l (its index `id`, its footprint
 // `emask` over the wave's pixels) and has parked its record at ent[l]; the body sets `done` for finished pixels.
@@ -3878,14 +4023,13 @@ static int fr_forward_impl(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	p.key_capacity = binning_capacity;
 	if ((rc = fr_bin_pipeline(p, g, s))) return rc;
 	const float* feat = g->colors_precomp ? g->colors_precomp : p.rgb;
-	if (features2)
-		hipLaunchKernelGGL((k_render_forward<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0,
-		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_color, out_depth,
-		                   features2, out_features2);
-	else
-		hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0,
-		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_color, out_depth,
-		                   (const float*)nullptr, (float*)nullptr);
+	const bool bcast = fr_debug_mode() == 16;        // FR_DEBUG_MODE=16: the wave-uniform compositing kernel of round 1 (A/B runs)
+	float* fT = (float*)((char*)image_ws + L.final_T);
+	uint32_t* nC = (uint32_t*)((char*)image_ws + L.n_contrib);
+	if (features2 && bcast) hipLaunchKernelGGL((k_render_forward<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, features2, out_features2);
+	else if (features2) hipLaunchKernelGGL((k_render_forward_walk<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, features2, out_features2);
+	else if (bcast) hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, (const float*)nullptr, (float*)nullptr);
+	else hipLaunchKernelGGL((k_render_forward_walk<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, (const float*)nullptr, (float*)nullptr);
 	if ((rc = fr_check_launch("k_render_forward"))) return rc;
 	(void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
 	return FR_OK;
@@ -4028,9 +4172,14 @@ extern "C" int fr_forward_features(const fr_raster_cfg* cfg, const float* featur
 	FrParams p;
 	fr_fill_params(p, cfg, &g0, 1);
 	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
-	hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
-	                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr,
-	                   (const float*)nullptr, (float*)nullptr);
+	if (fr_debug_mode() == 16)
+		hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
+		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr,
+		                   (const float*)nullptr, (float*)nullptr);
+	else
+		hipLaunchKernelGGL((k_render_forward_walk<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
+		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr,
+		                   (const float*)nullptr, (float*)nullptr);
 	return fr_check_launch("k_render_forward(features)");
 }
 
