@@ -3729,7 +3729,7 @@ struct FrLayout {
 	// geometry
 	size_t splat, cov3D, rgb, clamped, packed, geom_bytes;
 	// image
-	size_t tile_cnt, tile_off, tile_fill, final_T, n_contrib, status, big_list, img_bytes;
+	size_t tile_cnt, tile_off, tile_fill, final_T, n_contrib, status, big_list, blk_base, img_bytes;
 	// binning
 	size_t keys, bin_bytes;
 };
@@ -3754,6 +3754,9 @@ static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t ma
 	L.n_contrib = o; o = fr_align(o + (size_t)(V * W * H) * 4);
 	L.status = o; o = fr_align(o + 64);
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
+	// start of every projection workgroup's range inside a tile segment (k_preprocess claims it, k_scatter_keys then neither counts
+	// nor claims again); only while the tile histogram fits LDS
+	L.blk_base = o; o = fr_align(o + (T <= FR_MAX_LDS_TILES ? (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4 : 0));
 	L.img_bytes = o;
 	L.keys = 0;
 	L.bin_bytes = fr_align((size_t)(max_rendered > 0 ? max_rendered : 1) * 8);
@@ -3993,6 +3996,7 @@ static void fr_carve_single(FrParams& p, const FrLayout& L, char* geom, char* bi
 	p.tile_fill = (uint32_t*)(img + L.tile_fill);
 	p.status = (int*)(img + L.status);
 	p.big_list = (uint32_t*)(img + L.big_list);
+	p.blk_base = p.T <= FR_MAX_LDS_TILES ? (uint32_t*)(img + L.blk_base) : nullptr;
 	p.keys = (uint64_t*)(bin + L.keys);
 }
 
