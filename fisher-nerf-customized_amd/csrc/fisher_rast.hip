@@ -3,24 +3,29 @@
 //
 // Pipeline (single view: V = 1; Fisher scorer: V candidate views in one launch):
 //   k_cov3d              once per call      scale/quaternion -> cov3D[P][6]            (forward.cu:118-152)
+//   k_pack_static        once per call      records modes: one 64 / 128-byte record per Gaussian (mean, cov3D, rgb, ..., H_inv)
 //   k_preprocess         (P/(256 G), V)     project, cull, conic, radius, tile rect, per-tile COUNT through an LDS histogram
-//   k_preprocess_views   (P/(256 G), V/VC)  the same for many views of one camera: near-plane compaction, dense projection,
-//                                           compact visible lists                      (forward.cu:155-256)
+//   k_preprocess_views   (P/(256 G), V/VC)  the same for many views of one camera: near-plane + early frustum test, compaction,
+//                                           dense projection, compact visible lists, and (records modes) the scorer's
+//                                           per-(view, Gaussian) records                (forward.cu:155-256)
 //   k_scan_tiles         1 block            exclusive scan of the V*T tile counts -> segment offsets, device-side
 //                                           num_rendered / overflow flag (replaces cub::InclusiveSum + the blocking
 //                                           cudaMemcpy of rasterizer_impl.cu:277-282)
 //   k_scatter_keys/_vis  (P/(256 G), V)     emit (depth_bits<<32 | gaussian) into the tile's segment
 //                                           (duplicateWithKeys, rasterizer_impl.cu:70-111)
-//   k_sort_tiles/_mid/_big                  per-tile bitonic network in LDS on the 64-bit keys: replaces the global
+//   k_sort_tiles/_mid/_big                  per-tile bitonic network on the 64-bit keys, in registers (DPP / permlane exchanges
+//                                           between lanes, LDS only where waves' runs join): replaces the global
 //                                           cub::DeviceRadixSort (rasterizer_impl.cu:304-309).  Keys are unique, so the
 //                                           result equals the reference's stable (tile, depth) order with ties by index.
-//   k_render_forward<3|6>  (T, V)           alpha compositing, median depth, wave-private strips (forward.cu:261-393)
+//   k_render_forward_walk<3|6>  (T, V)      alpha compositing, median depth, wave-private strips, per-lane walk (forward.cu:261-393)
 //   k_backward_lin_tile<pair> + k_backward_finish   grad_power 1 (training): per-splat sums of the screen-space gradients,
 //                                           Jacobian chain once per Gaussian           (backward.cu:850-1140, 276-583)
 //   k_backward_tile      (T, 1)             generic fused backward, any grad_power, SH colours
-//   k_fisher_tile_v2<4|11|25>  T*V          transmittance pass + backward(power=2) fused, wave-private: sum(cur_H * H_inv) per
-//                                           view (gaussian.py:1548-1556, 1367) without materialising any gradient tensor,
-//                                           or cur_H / all 25 leaves accumulated (out_H modes)
+//   k_fisher_tile_v3     T*V                the scorer: sum(cur_H * H_inv) per view (gaussian.py:1548-1556, 1367) in ONE front-to-back
+//                                           pass over the records, no gradient tensor materialised
+//   k_fisher_tile_v3h    T*V                cur_H itself (4 columns): two front-to-back passes over the records
+//   k_fisher_tile_v2<4|11|25>  T*V          transmittance pass + backward(power=2) fused, wave-private: the other out_H modes
+//                                           (11 columns, gradient images, all 25 leaves of the rasteriser's power-2 backward)
 //   k_fisher_tile        T*V                first-generation scan kernel: fallback for tiles beyond the LDS index of the above
 //   k_knn_*                                 simple-knn distCUDA2
 //
