@@ -3606,6 +3606,194 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_tile(FrParams p, Fr
 	}
 }
 
+// k_backward_lin_tile with the scorer's machinery, and without its first pass: final_T and the position of every pixel's last
+// contributor come from the forward pass (image workspace: final_T, n_contrib -- what the reference's backward reads too), so
+// the wave goes straight to the back-to-front pass.  It streams the tile's keys from the END, keeps the splats whose alpha
+// footprint box meets its strip in an LDS ring (descending list position), and takes 64 of them at a time: records parked in
+// LDS, footprint masks, 64 x 64 bit transpose, and every pixel-lane walks ITS set bits (ds_read_b128 of the record; the
+// old kernel ran this walk wave-uniformly with a dozen ds_bpermute per step, after a wave-uniform first pass that rebuilt
+// final_T and a per-wave contributor list in 30 KiB of LDS).  Per pair the arithmetic is k_backward_lin_tile's.
+// No list capacity, hence no fallback tiles.
+template <bool PAIR>
+__global__ __launch_bounds__(FR_THREADS) void k_backward_lin_walk(FrParams p, FrBwdArgs b)
+{
+	constexpr int NCH = PAIR ? 6 : 3;
+	constexpr int NACC = PAIR ? 14 : 9;          // m2x, m2y, qx, qy, qw, dcolor[NCH], dopacity, (m2x, m2y of the second image)
+	constexpr int EF4 = PAIR ? 5 : 3;            // float4 per parked record (4 would repeat the LDS banks after four records)
+	__shared__ uint2 s_q[4][FR_QCAP];            // ring of {index, position in the tile's list}
+	__shared__ float4 s_ent[4][64][EF4];
+	__shared__ double s_acc[4][NACC][64];        // double: ds_add_f64 is ~20x faster than ds_add_f32 on MI355X (tools/lds_atomic_rate.hip)
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const uint32_t n = p.tile_cnt[tile];
+	const uint64_t* gk = p.keys + p.tile_off[tile];
+	const float4* splat = (const float4*)p.splat;
+	uint2* wq = s_q[wave];
+	float4 (*ent)[EF4] = s_ent[wave];
+
+	const size_t HW = (size_t)p.H * p.W;
+	const size_t pix = (size_t)p.W * pxy + pxx;
+	const float T_final = inside ? b.final_T[pix] : 0.f;
+	const uint32_t ncontrib = inside ? b.n_contrib[pix] : 0u;     // 1 + list position of the pixel's last contributor
+	float Tc = T_final, last_alpha = 0.f;
+	float accum[NCH], lastc[NCH], g[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { accum[c] = 0.f; lastc[c] = 0.f; g[c] = 0.f; }
+	if (inside)
+	{
+		g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix];
+		if constexpr (PAIR) { g[3] = b.dL_dpix2[pix]; g[4] = b.dL_dpix2[HW + pix]; g[5] = b.dL_dpix2[2 * HW + pix]; }
+	}
+	const float bg_dot_a = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
+	const float bg_dot_b = PAIR ? (p.bg[0] * g[3] + p.bg[1] * g[4] + p.bg[2] * g[5]) : 0.f;
+	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+	// nothing in front of the wave's deepest last contributor can be skipped, everything behind it can
+	uint32_t nmax = ncontrib;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o, 64); nmax = t > nmax ? t : nmax; }
+	nmax = nmax < n ? nmax : n;
+
+	uint32_t qh = 0, qn = 0;
+	int base = nmax > 0u ? (int)((nmax - 1u) & ~63u) : -64;      // blocks of 64 list positions, last one first
+	while (true)
+	{
+		// ---- stream (backwards): fill the ring up to one chunk, deepest first
+		while (qn < 64u && base >= 0)
+		{
+			const uint32_t pos = (uint32_t)base + (uint32_t)lane;
+			bool ov = false;
+			uint32_t id = 0;
+			if (pos < nmax)
+			{
+				id = (uint32_t)gk[pos];
+				const float4 q0 = splat[2 * (size_t)id], q1 = splat[2 * (size_t)id + 1];
+				const uint32_t eb = __float_as_uint(q1.w);
+				const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+				const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+				ov = hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi) && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
+			}
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			// descending position: the survivors of the higher lanes go first
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(lane < 63 ? (om >> (lane + 1)) : 0ull)) & (FR_QCAP - 1)] = make_uint2(id, pos);
+			qn += (uint32_t)__popcll(om);
+			base -= 64;
+		}
+		if (qn == 0) break;
+		// ---- chunk: up to 64 candidates, one per lane (lane 0 the deepest)
+		const uint32_t m = qn < 64u ? qn : 64u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int c = 0; c < NACC; c++) s_acc[wave][c][lane] = 0.0;
+		unsigned long long emask = 0ull;
+		uint32_t my_id = 0;
+		if ((uint32_t)lane < m)
+		{
+			const uint2 qe = wq[(qh + lane) & (FR_QCAP - 1)];
+			my_id = qe.x;
+			const float4 q0 = splat[2 * (size_t)my_id], q1 = splat[2 * (size_t)my_id + 1];   // {x, y, conx, cony} {conz, opacity, depth, ext}
+			ent[lane][0] = q0;
+			ent[lane][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(qe.y));
+			ent[lane][2] = make_float4(b.colors[3 * (size_t)my_id], b.colors[3 * (size_t)my_id + 1], b.colors[3 * (size_t)my_id + 2], 0.f);
+			if constexpr (PAIR) ent[lane][3] = make_float4(b.colors2[3 * (size_t)my_id], b.colors2[3 * (size_t)my_id + 1], b.colors2[3 * (size_t)my_id + 2], 0.f);
+			const float4 a = make_float4(q0.x, q0.y, q1.w, __builtin_amdgcn_logf(q1.y));
+			const float4 b4 = make_float4(-0.5f * q0.z, -q0.w, -0.5f * q1.x, 0.f);
+			emask = fr_footprint_mask<16, 4>(a, b4, strip_lo, tile_x0);
+		}
+		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (!inside) mask = 0ull;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- walk, back to front (lane order of the chunk = descending list position)
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
+			if (__float_as_uint(r1.w) >= ncontrib) continue;          // behind the pixel's last contributor (backward.cu:951-957)
+			float rc[NCH];
+			rc[0] = r2.x; rc[1] = r2.y; rc[2] = r2.z;
+			if constexpr (PAIR) { const float4 r3 = ent[j][3]; rc[3] = r3.x; rc[4] = r3.y; rc[5] = r3.z; }
+			const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
+			const float dx = r0.x - pfx, dy = r0.y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			if (power > 0.0f || power < r1.z) continue;
+			const float G = fr_expf_inrange(power);
+			const float alpha = fminf(0.99f, o * G);
+			if (alpha < 1.0f / 255.0f) continue;
+			// backward.cu:978-1038, per image: dL_dalpha = sum_ch (c_ch - accum_ch) dL_dpix_ch T  (- T_final / (1 - alpha) bg . dL_dpix)
+			Tc = Tc / (1.f - alpha);
+			const float wcol = alpha * Tc;
+			float da = 0.f, db = 0.f;
+#pragma unroll
+			for (int c = 0; c < NCH; c++)
+			{
+				accum[c] = last_alpha * lastc[c] + (1.f - last_alpha) * accum[c];
+				lastc[c] = rc[c];
+				const float t = (rc[c] - accum[c]) * g[c];
+				if (c < 3) da += t; else db += t;
+			}
+			da *= Tc; db *= Tc;
+			last_alpha = alpha;
+			const float bgf = -T_final / (1.f - alpha);
+			if (bg_dot_a != 0.f) da += bgf * bg_dot_a;
+			if (PAIR && bg_dot_b != 0.f) db += bgf * bg_dot_b;
+			const float dL_dalpha = da + db;
+			const float dL_dG = o * dL_dalpha;
+			const float gdx = G * dx, gdy = G * dy;
+			const float dG_ddelx = -gdx * cx - gdy * cy, dG_ddely = -gdy * cz - gdx * cy;
+			// screen-space gradient of the first image (of the only image when !PAIR)
+			const float oa = PAIR ? o * da : dL_dG;
+			atomicAdd(&s_acc[wave][0][j], (double)(oa * dG_ddelx * ddelx_dx)); atomicAdd(&s_acc[wave][1][j], (double)(oa * dG_ddely * ddely_dy));
+			atomicAdd(&s_acc[wave][2][j], (double)(-0.5f * gdx * dx * dL_dG)); atomicAdd(&s_acc[wave][3][j], (double)(-0.5f * gdx * dy * dL_dG));
+			atomicAdd(&s_acc[wave][4][j], (double)(-0.5f * gdy * dy * dL_dG));
+#pragma unroll
+			for (int c = 0; c < NCH; c++) atomicAdd(&s_acc[wave][5 + c][j], (double)(wcol * g[c]));
+			atomicAdd(&s_acc[wave][5 + NCH][j], (double)(G * dL_dalpha));
+			if constexpr (PAIR)
+			{
+				const float ob = o * db;
+				atomicAdd(&s_acc[wave][12][j], (double)(ob * dG_ddelx * ddelx_dx)); atomicAdd(&s_acc[wave][13][j], (double)(ob * dG_ddely * ddely_dy));
+			}
+		}
+		__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if ((uint32_t)lane < m)
+		{
+			const size_t id = my_id;
+			float a;
+			if ((a = (float)s_acc[wave][0][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id, a);
+			if ((a = (float)s_acc[wave][1][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id + 1, a);
+			if ((a = (float)s_acc[wave][2][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id, a);
+			if ((a = (float)s_acc[wave][3][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 1, a);
+			if ((a = (float)s_acc[wave][4][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 3, a);
+			if ((a = (float)s_acc[wave][5][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id, a);
+			if ((a = (float)s_acc[wave][6][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 1, a);
+			if ((a = (float)s_acc[wave][7][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + 2, a);
+			if constexpr (PAIR)
+			{
+				if ((a = (float)s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id, a);
+				if ((a = (float)s_acc[wave][9][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 1, a);
+				if ((a = (float)s_acc[wave][10][lane]) != 0.f) atomicAdd(b.dL_dcolors2 + 3 * id + 2, a);
+				if ((a = (float)s_acc[wave][12][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id, a);
+				if ((a = (float)s_acc[wave][13][lane]) != 0.f) atomicAdd(b.dL_dmean2D_2 + 3 * id + 1, a);
+			}
+			if ((a = (float)s_acc[wave][5 + NCH][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
 // Per Gaussian: the Jacobian chain of backward.cu:276-475,532-583 applied ONCE to the summed u (power 1 only).
 template <bool HAS_SR, bool HAS_SH>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_finish(FrParams p, FrBwdArgs b, float* __restrict__ dL_dsh)
@@ -4108,16 +4296,27 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	{
 		// gradients: sum u per splat in the tile kernel, Jacobian chain once per Gaussian; tiles that do not fit the LDS
 		// index are redone (u only) by the scan kernel.  The flag array borrows tile_fill, which is dead after binning.
-		uint8_t* fallback = (uint8_t*)p.tile_fill;
-		hipLaunchKernelGGL((k_backward_lin_tile<false>), dim3(p.T), block, 0, s, p, b, fallback);
-		if ((rc = fr_check_launch("k_backward_lin_tile"))) return rc;
-		b.only_flagged = fallback;
-		b.u_only = 1;
-		if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
-		else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
-		else if (sh) hipLaunchKernelGGL((k_backward_tile<false, true>), grid, block, 0, s, p, b);
-		else hipLaunchKernelGGL((k_backward_tile<false, false>), grid, block, 0, s, p, b);
-		if ((rc = fr_check_launch("k_backward_tile(flagged)"))) return rc;
+		// FR_DEBUG_MODE=17: the two-pass tile kernel of round 1 with its fallback pass (A/B runs); k_backward_lin_walk has no list
+		// capacity and therefore no fallback tiles
+		if (fr_debug_mode() == 17)
+		{
+			uint8_t* fallback = (uint8_t*)p.tile_fill;
+			hipLaunchKernelGGL((k_backward_lin_tile<false>), dim3(p.T), block, 0, s, p, b, fallback);
+			if ((rc = fr_check_launch("k_backward_lin_tile"))) return rc;
+			b.only_flagged = fallback;
+			b.u_only = 1;
+			if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
+			else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
+			else if (sh) hipLaunchKernelGGL((k_backward_tile<false, true>), grid, block, 0, s, p, b);
+			else hipLaunchKernelGGL((k_backward_tile<false, false>), grid, block, 0, s, p, b);
+			if ((rc = fr_check_launch("k_backward_tile(flagged)"))) return rc;
+		}
+		else
+		{
+			hipLaunchKernelGGL((k_backward_lin_walk<false>), dim3(p.T), block, 0, s, p, b);
+			if ((rc = fr_check_launch("k_backward_lin_walk"))) return rc;
+			b.u_only = 1;
+		}
 		dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
 		if (sr && sh) hipLaunchKernelGGL((k_backward_finish<true, true>), gp, block, 0, s, p, b, dL_dsh);
 		else if (sr) hipLaunchKernelGGL((k_backward_finish<true, false>), gp, block, 0, s, p, b, dL_dsh);
@@ -4237,10 +4436,18 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	b.dL_dpix = dL_dout_color; b.colors = g->colors_precomp; b.dL_dmean2D = dL_dmeans2D; b.dL_dcolors = dL_dcolors;
 	b.dL_dpix2 = dL_dout_features; b.colors2 = features; b.dL_dmean2D_2 = dL_dmeans2D_features; b.dL_dcolors2 = dL_dfeatures;
 	b.only_flagged = nullptr; b.u_only = 0;
-	hipLaunchKernelGGL((k_backward_lin_tile<true>), dim3(p.T), block, 0, s, p, b, fallback);
+	// (the pair keeps the two-pass tile kernel: with fourteen accumulators per candidate the walk form measured 0.83 against
+	// 0.79 ms at 2M Gaussians / 512 x 512 -- the single image gains, 0.49 against 0.59; FR_DEBUG_MODE=18 forces the walk form)
+	const bool pair_walk = fr_debug_mode() == 18;
+	if (pair_walk)
+	{
+		hipLaunchKernelGGL((k_backward_lin_walk<true>), dim3(p.T), block, 0, s, p, b);
+		if ((rc = fr_check_launch("k_backward_lin_walk<pair>"))) return rc;
+	}
+	else hipLaunchKernelGGL((k_backward_lin_tile<true>), dim3(p.T), block, 0, s, p, b, fallback);
 	if ((rc = fr_check_launch("k_backward_lin_tile<pair>"))) return rc;
-	// tiles whose lists do not fit the LDS index: the scan kernel, once per image
-	for (int pass = 0; pass < 2; pass++)
+	// (two-pass kernel only) tiles whose lists do not fit the LDS index: the scan kernel, once per image
+	for (int pass = 0; pass < 2 && !pair_walk; pass++)
 	{
 		b.dL_dpix = pass ? dL_dout_features : dL_dout_color;
 		b.colors = pass ? features : g->colors_precomp;
