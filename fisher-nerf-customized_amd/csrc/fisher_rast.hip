@@ -492,13 +492,23 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 }
 
 // (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
-struct FrRecordArgs { const float* H_inv; long long hinv_stride; const float* packed; float4* recq; const float* cov_trace; };   // cov_trace [P] or null: trace of cov3D (k_pack_static), for the early frustum test
+struct FrRecordArgs {
+	const float* H_inv; long long hinv_stride; const float* packed; float4* recq;
+	const float* cov_trace;      // [P] or null: trace of cov3D (k_pack_static), for the early frustum test
+	// compact records (multi-view front end in a records mode), or null: one 96-byte record {recA, recB, recQ[4]} per SLOT,
+	// slot = projection workgroup * (256 G) + rank of the Gaussian among the workgroup's visible ones of that view -- monotone in
+	// the Gaussian index, so keys that carry the slot sort exactly like keys that carry the index, and a workgroup's records of a
+	// view form one dense run instead of being strewn over [P]
+	float4* comp;                // [V][PV][6], PV = workgroups * 256 G
+	uint32_t* slot_idx;          // [V][PV]: slot -> Gaussian index (k_fisher_tile_v3h flushes by index)
+};
 // floats per Gaussian of the packed static record (k_pack_static): {mean 3, cov3D 6, rgb 3, (scale 3, rot 4), H_inv C}
 template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
 template <int C, bool REWRITE, bool FORM_A = false>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
-                                                     const float* vm, const float* pm, const float* wm, bool has_w2c);
+                                                     const float* vm, const float* pm, const float* wm, bool has_w2c,
+                                                     float4* out6 = nullptr, const float4* ab_src = nullptr);
 
 // ---------------------------------------------------------------------------------------------------------
 // Multi-view front end of the Fisher path (same camera, one rigid transform per candidate view).
@@ -515,11 +525,15 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 template <int RC, bool PHASE_C>
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrRecordArgs ra)
 {
-	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12]
+	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12] | visible bitmap[VC][8 G] | its prefix popcounts[VC][8 G]
 	const int VC = p.VC;
 	uint32_t* hist = fr_dyn_lds;
 	uint32_t* pairs = hist + (size_t)VC * p.T;
 	float* s_wm = (float*)(pairs + FR_THREADS * VC);
+	const int W32 = 8 * p.G;                     // 32-bit words of a view's visibility bitmap over the workgroup's 256 G Gaussians
+	uint32_t* s_bm = (uint32_t*)(s_wm + 12 * VC);
+	uint32_t* s_pf = s_bm + VC * W32;
+	const bool compact = RC != 0 && ra.comp != nullptr;
 	__shared__ uint32_t s_np;
 	__shared__ uint32_t s_n[16];
 	__shared__ uint32_t s_ref[16];               // tile instances by the reference's rule (radius rectangle), per view
@@ -533,6 +547,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	if (has_w2c) for (int t = tid; t < nv * 12; t += FR_THREADS) s_wm[t] = p.w2c[16 * (size_t)(v0 + t / 12) + (t % 12)];
 	if (tid < 16) { s_n[tid] = 0; s_ref[tid] = 0; }
 	if (tid == 0) s_np = 0;
+	if (compact) for (int t = tid; t < nv * W32; t += FR_THREADS) s_bm[t] = 0u;
 	float vm[16], pm[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
@@ -634,7 +649,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 			{
 				const float o = p.opac[i];
 				const uint32_t ext = fr_alpha_extent(s.conx, s.cony, s.conz, o);
+				const uint32_t slot = atomicAdd(&s_n[vv], 1u);          // position in this workgroup's list of the view
 				float4* dst = (float4*)(p.splat + (size_t)v * p.P + i);
+				if (compact)
+				{
+					// {recA, recB} wait beside the list entry (the [V][P] splat region serves as [V][workgroup][256 G] here) until
+					// phase C knows the Gaussian's rank among the workgroup's visible ones
+					dst = (float4*)(p.splat + ((size_t)v * nblk + blockIdx.x) * cap + slot);
+					const uint32_t local = (uint32_t)(i - (int)(blockIdx.x * cap));
+					atomicOr(&s_bm[vv * W32 + (int)(local >> 5)], 1u << (local & 31u));
+				}
 				if constexpr (RC != 0)
 				{
 					// score-only mode: the scorer's {recA, recB} form straight away (see k_fisher_tile_v3)
@@ -670,7 +694,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 				for (uint32_t y = ry0; y < ry1; y++)
 					for (uint32_t x = rx0; x < rx1; x++)
 						atomicAdd(&h[y * p.gx + x], 1u);
-				const uint32_t slot = atomicAdd(&s_n[vv], 1u);
 				FrVisEntry en;
 				en.idx = (uint32_t)i; en.depth_bits = fr_as_u32(s.depth);
 				en.xy0 = rx0 | (ry0 << 16); en.xy1 = rx1 | (ry1 << 16);
@@ -704,16 +727,43 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	{
 		// ---- phase C: the entries and splat records were written by this workgroup (same CU, same L1): visible after a barrier
 		__syncthreads();
+		if (compact)
+		{
+			// exclusive prefix popcounts of the bitmaps: rank of a Gaussian = prefix of its word + popcount of the lower bits
+			for (int t = tid; t < nv * W32; t += FR_THREADS)
+			{
+				const int vv = t / W32, w = t - vv * W32;
+				uint32_t acc = 0;
+				for (int u = 0; u < w; u++) acc += (uint32_t)__popc(s_bm[vv * W32 + u]);
+				s_pf[t] = acc;
+			}
+			__syncthreads();
+		}
+		const size_t PV = (size_t)nblk * cap;
 		for (int vv = 0; vv < nv; vv++)
 		{
 			const int v = v0 + vv;
 			const uint32_t n = s_n[vv];
-			const FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap;
+			FrVisEntry* list = p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap;
 			float wm[12];
 #pragma unroll
 			for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * vv + k] : 0.f;
 			for (uint32_t e = tid; e < n; e += FR_THREADS)
-				fr_fisher_record_one<(RC < 0 ? -RC : RC), false, (RC < 0)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, list[e].idx, vm, pm, wm, has_w2c);
+			{
+				const uint32_t idx = list[e].idx;
+				if (compact)
+				{
+					const uint32_t local = idx - blockIdx.x * cap;
+					const uint32_t rank = s_pf[vv * W32 + (int)(local >> 5)] + (uint32_t)__popc(s_bm[vv * W32 + (int)(local >> 5)] & ((1u << (local & 31u)) - 1u));
+					const uint32_t slot = blockIdx.x * cap + rank;
+					const float4* tmp = (const float4*)(p.splat + ((size_t)v * nblk + blockIdx.x) * cap + e);
+					fr_fisher_record_one<(RC < 0 ? -RC : RC), false, (RC < 0)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c,
+					                                                           ra.comp + ((size_t)v * PV + slot) * 6, tmp);
+					list[e].idx = slot;                                  // the keys carry the slot from here on
+					if constexpr (RC < 0) ra.slot_idx[(size_t)v * PV + slot] = idx;   // (only k_fisher_tile_v3h goes back to the index)
+				}
+				else fr_fisher_record_one<(RC < 0 ? -RC : RC), false, (RC < 0)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c);
+			}
 		}
 	}
 }
@@ -1423,6 +1473,12 @@ struct FrFisherArgs {
 	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
 	const uint8_t* only_flagged; // [V][T] or null: when set, k_fisher_tile handles only the flagged tiles
 	int debug_mode;              // FR_DEBUG_MODE env (timing ablations only): 1 = k_fisher_tile_v2 stops after pass 1
+	// the scorer's records as k_fisher_tile_v3 / _v3h address them: record r of view v has {recA, recB} at recA[v * ab_view + r * ab_stride]
+	// (+ 1) and its four recQ float4 at recQ[v * q_view + r * q_stride + k] -- two dense [V][P] arrays (strides 2 and 4), or the
+	// compact 96-byte records (both strides 6, r = slot); slot_idx [V][slot_view] maps a slot back to the Gaussian index, or null
+	const float4* recA; long long ab_view; int ab_stride;
+	const float4* recQ; long long q_view; int q_stride;
+	const uint32_t* slot_idx; long long slot_view;
 };
 
 template <int C, bool HAS_HINV, bool HAS_OUTH>
@@ -2268,7 +2324,8 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 template <int C, bool REWRITE, bool FORM_A>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
-                                                     const float* vm, const float* pm, const float* wm, bool has_w2c)
+                                                     const float* vm, const float* pm, const float* wm, bool has_w2c,
+                                                     float4* out6, const float4* ab_src)
 {
 	constexpr int PS = FrPackSize<C>::value;
 	constexpr bool SR = C >= 11;
@@ -2322,11 +2379,12 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 			sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
 			sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
 		}
-		float4* da = recq + ((size_t)v * p.P + id) * 4;
+		float4* da = out6 ? out6 + 2 : recq + ((size_t)v * p.P + id) * 4;
 		da[0] = make_float4(Ap[0][0], Ap[0][1], Ap[0][2], Ap[0][3]);
 		da[1] = make_float4(Ap[0][4], Ap[1][0], Ap[1][1], Ap[1][2]);
 		da[2] = make_float4(Ap[1][3], Ap[1][4], Ap[2][0], Ap[2][1]);
 		da[3] = make_float4(Ap[2][2], Ap[2][3], Ap[2][4], inv_oa * inv_oa);
+		if (out6) { out6[0] = ab_src[0]; out6[1] = ab_src[1]; }          // compact record: {recA, recB} travel with the coefficients
 		return;
 	}
 	float hv[C];
@@ -2389,11 +2447,12 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	const float c12 = qf[3] * pb0 + qf[4] * pa0 + qf[7] * pb1 + qf[8] * pa1;
 	const float c03 = qf[4] * pb0 + qf[8] * pb1;
 	const float c40 = qf[9], c31 = qf[10], c22 = qf[11] + qf[12], c13 = qf[13], c04 = qf[14];
-	float4* dq = recq + ((size_t)v * p.P + id) * 4;
+	float4* dq = out6 ? out6 + 2 : recq + ((size_t)v * p.P + id) * 4;
 	dq[0] = make_float4(c02, c03, c04, c11);
 	dq[1] = make_float4(c12, c13, c20, c21);
 	dq[2] = make_float4(c22, c30, c31, c40);
 	dq[3] = make_float4(k3, 0.f, 0.f, 0.f);
+	if (out6) { out6[0] = ab_src[0]; out6[1] = ab_src[1]; }              // compact record: {recA, recB} travel with the coefficients (loaded late: fewer live registers)
 }
 
 // Stand-alone form of phase C of k_preprocess_views, for the single-view front end (images beyond FR_MAX_LDS_TILES tiles,
@@ -2524,8 +2583,10 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	const size_t vP = (size_t)v * p.P;
 	const uint32_t n = p.tile_cnt[vt];
 	const uint64_t* gk = p.keys + p.tile_off[vt];
-	const float4* rec = (const float4*)(p.splat + vP);
-	const float4* rq = recq + vP * 4;
+	(void)vP; (void)recq;
+	const float4* rec = f.recA + (size_t)v * f.ab_view;
+	const float4* rq = f.recQ + (size_t)v * f.q_view;
+	const size_t rsA = (size_t)f.ab_stride, rsQ = (size_t)f.q_stride;
 	uint32_t* wq = s_q[wave];
 	float4 (*ent)[FR_ENT3_F4] = s_ent[wave];
 	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];   // LDS byte address
@@ -2545,7 +2606,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	// software pipeline of the key stream: id1 / r1 = indices and recA of the chunk at `base`, id2 = indices of the next one
 	uint32_t id1 = 0, id2 = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[2 * (size_t)id1]; }
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[rsA * id1]; }
 	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
 	uint32_t base = 0;
 	// ---- stream: fill the queue up to one chunk
@@ -2557,7 +2618,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		{
 			const uint32_t idc = id1; const float4 rc = r1;
 			id1 = id2;
-			if (base + 64 + lane < n) r1 = rec[2 * (size_t)id2];
+			if (base + 64 + lane < n) r1 = rec[rsA * id2];
 			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
 			const uint32_t eb = __float_as_uint(rc.z);
 			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
@@ -2585,9 +2646,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		if ((uint32_t)lane < pm)
 		{
 			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
-			pa = rec[2 * (size_t)id]; pb = rec[2 * (size_t)id + 1];
-			pq0 = rq[4 * (size_t)id]; pq1 = rq[4 * (size_t)id + 1]; pq2 = rq[4 * (size_t)id + 2];
-			pk3 = ((const float*)(rq + 4 * (size_t)id + 3))[0];
+			pa = rec[rsA * id]; pb = rec[rsA * id + 1];
+			pq0 = rq[rsQ * id]; pq1 = rq[rsQ * id + 1]; pq2 = rq[rsQ * id + 2];
+			pk3 = ((const float*)(rq + rsQ * id + 3))[0];
 		}
 		qh = (qh + pm) & (FR_QCAP - 1); qn -= pm;
 	};
@@ -2946,15 +3007,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 // body(m, id, emask) runs once per chunk of m <= 64 candidates: lane l < m holds candidate l (its index `id`, its footprint
 // `emask` over the wave's pixels) and has parked its record at ent[l]; the body sets `done` for finished pixels.
 template <int BW, int BH, int NQ, class Body>
-__device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, uint32_t n, const float4* __restrict__ rec,
-                                              const float4* __restrict__ rq, uint32_t* wq, float4 (*ent)[FR_ENT_F4],
+__device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, uint32_t n, const float4* __restrict__ rec, size_t sA,
+                                              const float4* __restrict__ rq, size_t sQ, uint32_t* wq, float4 (*ent)[FR_ENT_F4],
                                               int lane, float strip_lo, float tile_x0, bool& done, Body body)
 {
 	const float strip_hi = strip_lo + (float)(BH - 1), tile_x1 = tile_x0 + (float)(BW - 1);
 	uint32_t qh = 0, qn = 0;
 	uint32_t id1 = 0, id2 = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[2 * (size_t)id1]; }
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[sA * id1]; }
 	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
 	uint32_t base = 0;
 	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
@@ -2964,7 +3025,7 @@ __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, u
 		{
 			const uint32_t idc = id1; const float4 rc = r1;
 			id1 = id2;
-			if (base + 64 + lane < n) r1 = rec[2 * (size_t)id2];
+			if (base + 64 + lane < n) r1 = rec[sA * id2];
 			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
 			const uint32_t eb = __float_as_uint(rc.z);
 			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
@@ -2985,10 +3046,10 @@ __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, u
 		if ((uint32_t)lane < m)
 		{
 			my_id = wq[(qh + lane) & (FR_QCAP - 1)];
-			const float4 a = rec[2 * (size_t)my_id], b4 = rec[2 * (size_t)my_id + 1];
+			const float4 a = rec[sA * my_id], b4 = rec[sA * my_id + 1];
 			ent[lane][0] = a; ent[lane][1] = b4;
 #pragma unroll
-			for (int k = 0; k < NQ; k++) ent[lane][2 + k] = rq[4 * (size_t)my_id + k];
+			for (int k = 0; k < NQ; k++) ent[lane][2 + k] = rq[sQ * my_id + k];
 			emask = fr_footprint_mask<BW, BH>(a, b4, strip_lo, tile_x0);
 		}
 		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
@@ -3024,8 +3085,11 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	const size_t vP = (size_t)v * p.P;
 	const uint32_t n = p.tile_cnt[vt];
 	const uint64_t* gk = p.keys + p.tile_off[vt];
-	const float4* rec = (const float4*)(p.splat + vP);
-	const float4* rq = recq + vP * 4;
+	(void)vP; (void)recq;
+	const float4* rec = f.recA + (size_t)v * f.ab_view;
+	const float4* rq = f.recQ + (size_t)v * f.q_view;
+	const size_t sA = (size_t)f.ab_stride, sQ = (size_t)f.q_stride;
+	const uint32_t* slot_idx = f.slot_idx ? f.slot_idx + (size_t)v * f.slot_view : nullptr;
 	uint32_t* wq = s_q[wave];
 	float4 (*ent)[FR_ENT_F4] = s_ent[wave];
 	double (*acc)[64] = s_acc[wave];
@@ -3036,7 +3100,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	float T = 1.0f;
 	double Cg = 0.0;
 	bool done = !inside;
-	fr_strip_pass<BW, BH, 0>(gk, n, rec, rq, wq, ent, lane, strip_lo, tile_x0, done,
+	fr_strip_pass<BW, BH, 0>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done,
 		[&](uint32_t, uint32_t, unsigned long long emask) {
 			unsigned long long mask = fr_wave_transpose64(emask, lane);
 			if (done) mask = 0ull;
@@ -3087,7 +3151,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 		}
 		return kill;
 	};
-	fr_strip_pass<BW, BH, 4>(gk, n, rec, rq, wq, ent, lane, strip_lo, tile_x0, done,
+	fr_strip_pass<BW, BH, 4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done,
 		[&](uint32_t m, uint32_t my_id, unsigned long long emask) {
 #pragma unroll
 			for (int c = 0; c < 4; c++) acc[c][lane] = 0.0;
@@ -3110,13 +3174,14 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 			__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			// flush: consecutive lanes on consecutive columns of one Gaussian
+			// flush: consecutive lanes on consecutive columns of one Gaussian (compact records: the candidate's slot back to its index)
+			const uint32_t real_id = (slot_idx && (uint32_t)lane < m) ? slot_idx[my_id] : my_id;
 #pragma unroll
 			for (int i = 0; i < 4; i++)
 			{
 				const int flat = i * 64 + lane;
 				const int e = flat >> 2, c = flat & 3;
-				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)my_id);
+				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)real_id);
 				const float a = ((uint32_t)e < m) ? (float)acc[c][e] * dL2 : 0.f;
 				if (a != 0.f) atomicAdd(dst + (size_t)id_e * 4 + c, a);
 			}
@@ -4119,8 +4184,8 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	if (multi)
 	{
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
-		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC) * 4;
-		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr };
+		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 2 * (size_t)p.VC * 8 * (size_t)p.G) * 4;
+		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr };
 		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
@@ -4480,7 +4545,8 @@ static int fr_debug_mode()
 }
 
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, recq, packed, cov_trace, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t PV;                   // slots per view of the compact records: projection workgroups * 256 G (>= P)
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
 {
@@ -4493,8 +4559,13 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	const size_t nblk_v = (size_t)((P + FR_THREADS * fr_pick_G_views(P) - 1) / (FR_THREADS * fr_pick_G_views(P)));
 	L.radii = o; o = fr_align(o + (size_t)V * nblk_v * (size_t)(FR_THREADS * fr_pick_G_views(P)) * sizeof(FrVisEntry));
 	L.vis_n = o; o = fr_align(o + (size_t)V * nblk_v * 4);
-	L.splat = o; o = fr_align(o + VP * sizeof(FrSplat));
-	L.recq = o; o = fr_align(o + VP * 64);                // k_fisher_records: 12 polynomial coefficients + k3 (or A'[15], 1/o^2) per (view, Gaussian), written where visible
+	// [V][P] 32-byte splat records; with compact records the same region is [V][workgroup][256 G] (phase B parks {recA, recB} there)
+	L.PV = nblk_v * (size_t)(FR_THREADS * fr_pick_G_views(P));
+	const size_t VPV = (size_t)V * (L.PV > (size_t)P ? L.PV : (size_t)P);
+	L.splat = o; o = fr_align(o + VPV * sizeof(FrSplat));
+	// dense: [V][P] x 64 B {12 polynomial coefficients + k3, or A'[15], 1/o^2}; compact: [V][PV] x 96 B {recA, recB, the same}
+	L.recq = o; o = fr_align(o + VPV * 96);
+	L.slot_idx = o; o = fr_align(o + VPV * 4);
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.cov_trace = o; o = fr_align(o + (size_t)P * 4);
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
@@ -4663,6 +4734,22 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	plan.columns = fc->columns;
 	plan.ra.H_inv = fc->H_inv; plan.ra.hinv_stride = fc->H_inv_view_stride;
 	plan.ra.packed = (const float*)(ws + L.packed); plan.ra.recq = (float4*)(ws + L.recq);
+	// compact records with the multi-view front end (the same condition fr_bin_pipeline uses for it); FR_DEBUG_MODE=19: dense (A/B runs)
+	const bool compact = (v3 || v3h) && p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES && f.debug_mode != 19;
+	plan.ra.comp = compact ? (float4*)(ws + L.recq) : nullptr;
+	plan.ra.slot_idx = (compact && v3h) ? (uint32_t*)(ws + L.slot_idx) : nullptr;
+	if (compact)
+	{
+		f.recA = plan.ra.comp; f.ab_view = (long long)L.PV * 6; f.ab_stride = 6;
+		f.recQ = plan.ra.comp + 2; f.q_view = (long long)L.PV * 6; f.q_stride = 6;
+		f.slot_idx = plan.ra.slot_idx; f.slot_view = (long long)L.PV;
+	}
+	else
+	{
+		f.recA = (const float4*)p.splat; f.ab_view = (long long)P * 2; f.ab_stride = 2;
+		f.recQ = plan.ra.recq; f.q_view = (long long)P * 4; f.q_stride = 4;
+		f.slot_idx = nullptr; f.slot_view = 0;
+	}
 	// the early frustum test needs a positive semi-definite cov3D: the one k_cov3d builds, not a caller's precomputed one;
 	// FR_DEBUG_MODE=15 switches it off (A/B runs)
 	plan.ra.cov_trace = (g->cov3D_precomp || f.debug_mode == 15) ? nullptr : (const float*)(ws + L.cov_trace);
