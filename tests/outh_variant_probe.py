@@ -26,3 +26,6 @@ sc = FisherScorer(cam, act["means3D"], act["rgb_colors"], act["rotations"], act[
 out = torch.zeros((V, P, 4), device=dev)
 sc.run(w2c, out_H=out, out_H_per_view=True)
 np.save(sys.argv[1], out.cpu().numpy())
+# ... and the scores of the same views with fixed weights (compared bit for bit between the record layouts)
+H_inv = (torch.rand((P, 4), generator=torch.Generator().manual_seed(3)) * 2.0 + 0.05).to(dev)
+np.save(sys.argv[1].replace(".npy", "_scores.npy"), sc.run(w2c, H_inv=H_inv)["scores"].cpu().numpy())
