@@ -4552,7 +4552,6 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 {
 	FrFisherLayout L;
 	const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
-	const size_t VP = (size_t)(V * P);
 	size_t o = 0;
 	// radii [V][P] int32 (single-pass front end, images beyond FR_MAX_LDS_TILES tiles) and the compact visible lists
 	// [V][blocks][256 G] x 16 B of the multi-view front end share one region: a launch runs one or the other
