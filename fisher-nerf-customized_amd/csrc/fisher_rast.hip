@@ -2340,39 +2340,25 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	for (int q = 0; q < PS / 4; q++) { const float4 t4 = pk[q]; gsv[4 * q] = t4.x; gsv[4 * q + 1] = t4.y; gsv[4 * q + 2] = t4.z; gsv[4 * q + 3] = t4.w; }
 	const fr_f3 pw = { gsv[0], gsv[1], gsv[2] };
 	const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
-	float A[3][5];
-	float B[6][3];
-	float cov2d[3];
-	fr_mean_jacobian<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, A, SR ? B : nullptr, cov2d);
-	// columns pre-scaled so that the walk can feed them u' = (-(cx dx + cy dy), -(cz dy + cy dx), dx^2, dx dy, dy^2):
-	// (dL_dmean2D.xy, dL_dconic.xyw) = w * (ddelx_dx u'0, ddely_dy u'1, -u'2/2, -u'3/2, -u'4/2), w = opacity G dL_dalpha
-	const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
-	float Ap[3][5];
-#pragma unroll
-	for (int r = 0; r < 3; r++)
-	{
-		Ap[r][0] = A[r][0] * ddelx_dx; Ap[r][1] = A[r][1] * ddely_dy;
-#pragma unroll
-		for (int c = 2; c < 5; c++) Ap[r][c] = -0.5f * A[r][c];
-	}
-	float Cp[SR ? 7 : 1][3];
+	// The per-Gaussian rows of the leaves over gamma(u) = (ux, uy, ux^2, ux uy, uy^2), u = -conic d (fr_math.h: the basis in which
+	// the chain of backward.cu:335-475 has no structural cancellation; written in (dx, dy) a needle-shaped splat loses the
+	// square of its conic's condition number).
+	float Rg[3][5];
+	float Bg[6][3];
+	fr_mean_rows_g<true>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, p.W, p.H, Rg, SR ? Bg : nullptr, nullptr, nullptr);
+	float Cg[SR ? 7 : 1][3];
 	int go = 12;
 	if constexpr (SR)
 	{
 		const fr_f3 sc = { gsv[12], gsv[13], gsv[14] };
 		const fr_f4 qr = { gsv[15], gsv[16], gsv[17], gsv[18] };
-		float Cm[7][3];
-		fr_scale_rot_jacobian(sc, p.mod, qr, B, Cm);
-#pragma unroll
-		for (int r = 0; r < 7; r++)
-#pragma unroll
-			for (int c = 0; c < 3; c++) Cp[r][c] = -0.5f * Cm[r][c];
+		fr_scale_rot_jacobian(sc, p.mod, qr, Bg, Cg);
 		go = 19;
 	}
 	if constexpr (FORM_A)
 	{
 		// out_H mode (k_fisher_tile_v3h): the walk needs the three mean rows themselves, not their H_inv-weighted form
-		static_assert(!FORM_A || C == 4, "the A-form record holds the 3 x 5 mean Jacobian only");
+		static_assert(!FORM_A || C == 4, "the A-form record holds the 3 x 5 mean rows only");
 		const float inv_oa = __builtin_amdgcn_rcpf(opacity);
 		if constexpr (REWRITE)
 		{
@@ -2380,10 +2366,10 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 			sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
 		}
 		float4* da = out6 ? out6 + 2 : recq + ((size_t)v * p.P + id) * 4;
-		da[0] = make_float4(Ap[0][0], Ap[0][1], Ap[0][2], Ap[0][3]);
-		da[1] = make_float4(Ap[0][4], Ap[1][0], Ap[1][1], Ap[1][2]);
-		da[2] = make_float4(Ap[1][3], Ap[1][4], Ap[2][0], Ap[2][1]);
-		da[3] = make_float4(Ap[2][2], Ap[2][3], Ap[2][4], inv_oa * inv_oa);
+		da[0] = make_float4(Rg[0][0], Rg[0][1], Rg[0][2], Rg[0][3]);
+		da[1] = make_float4(Rg[0][4], Rg[1][0], Rg[1][1], Rg[1][2]);
+		da[2] = make_float4(Rg[1][3], Rg[1][4], Rg[2][0], Rg[2][1]);
+		da[3] = make_float4(Rg[2][2], Rg[2][3], Rg[2][4], inv_oa * inv_oa);
 		if (out6) { out6[0] = ab_src[0]; out6[1] = ab_src[1]; }          // compact record: {recA, recB} travel with the coefficients
 		return;
 	}
@@ -2399,58 +2385,21 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 #pragma unroll
 		for (int c = 0; c < C; c++) hv[c] = gsv[go + c];
 	}
-	// upper triangle of Q = sum_c H_inv[c] M_c^T M_c, row-major, off-diagonal entries doubled: u'^T Q u' = sum_{i <= j} Q'[ij] u_i u_j
-	float qf[16];
-	int q = 0;
-#pragma unroll
-	for (int i = 0; i < 5; i++)
-#pragma unroll
-		for (int j = i; j < 5; j++)
-		{
-			float acc = hv[0] * Ap[0][i] * Ap[0][j] + hv[1] * Ap[1][i] * Ap[1][j] + hv[2] * Ap[2][i] * Ap[2][j];
-			if constexpr (SR)
-			{
-				if (i >= 2)
-				{
-#pragma unroll
-					for (int r = 0; r < 7; r++) acc += hv[4 + r] * Cp[r][i - 2] * Cp[r][j - 2];
-				}
-			}
-			qf[q++] = (i == j) ? acc : 2.0f * acc;
-		}
+	// F(u) = sum_c H_inv[c] (R_c . gamma(u))^2 is a bivariate polynomial in (ux, uy) with terms of degree 2, 3 and 4 only: 12
+	// coefficients, which the walk evaluates by Horner's rule in 14 operations (26 for the quadratic form).
+	float qp[12];
+	fr_scorer_poly_g<C>(Rg, SR ? Cg : nullptr, hv, qp);
 	const float inv_o = __builtin_amdgcn_rcpf(opacity);
 	const float k3 = inv_o * inv_o * hv[3];              // dL_dopacity = G dL_dalpha = w / opacity, weighted by H_inv[3]
-	float hcx, ncy, hcz;                                  // (-conic.x / 2, -conic.y, -conic.z / 2)
 	if constexpr (REWRITE)
 	{
-		hcx = -0.5f * a0.z; ncy = -a0.w; hcz = -0.5f * a1.x;
 		sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
-		sp[1] = make_float4(hcx, ncy, hcz, gsv[9] + gsv[10] + gsv[11]);
+		sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
 	}
-	else
-	{
-		// the conic again (forward.cu:222-231), from the cov2D the Jacobian chain has just rebuilt -- not re-read from recB
-		const float ca = cov2d[0] + 0.3f, cb = cov2d[1], cc = cov2d[2] + 0.3f;
-		const float inv_det = __builtin_amdgcn_rcpf(ca * cc - cb * cb);
-		hcx = -0.5f * cc * inv_det; ncy = cb * inv_det; hcz = -0.5f * ca * inv_det;
-	}
-	// u' is a polynomial in d = mean - pixel: u'0 = a0 dx + b0 dy, u'1 = a1 dx + b1 dy, u'2..4 = dx^2, dx dy, dy^2, so the
-	// pair's factor u'^T Q u' is a bivariate polynomial with terms of degree 2, 3 and 4 only: 12 coefficients, which the walk
-	// evaluates by Horner's rule in 14 operations (26 for the quadratic form).  qf: Q' row-major upper triangle, (i, j) at
-	// 0 1 2 3 4 / 5 6 7 8 / 9 10 11 / 12 13 / 14.
-	const float pa0 = 2.0f * hcx, pb0 = ncy, pa1 = ncy, pb1 = 2.0f * hcz;
-	const float c20 = qf[0] * pa0 * pa0 + qf[1] * pa0 * pa1 + qf[5] * pa1 * pa1;
-	const float c11 = 2.0f * qf[0] * pa0 * pb0 + qf[1] * (pa0 * pb1 + pa1 * pb0) + 2.0f * qf[5] * pa1 * pb1;
-	const float c02 = qf[0] * pb0 * pb0 + qf[1] * pb0 * pb1 + qf[5] * pb1 * pb1;
-	const float c30 = qf[2] * pa0 + qf[6] * pa1;
-	const float c21 = qf[2] * pb0 + qf[3] * pa0 + qf[6] * pb1 + qf[7] * pa1;
-	const float c12 = qf[3] * pb0 + qf[4] * pa0 + qf[7] * pb1 + qf[8] * pa1;
-	const float c03 = qf[4] * pb0 + qf[8] * pb1;
-	const float c40 = qf[9], c31 = qf[10], c22 = qf[11] + qf[12], c13 = qf[13], c04 = qf[14];
 	float4* dq = out6 ? out6 + 2 : recq + ((size_t)v * p.P + id) * 4;
-	dq[0] = make_float4(c02, c03, c04, c11);
-	dq[1] = make_float4(c12, c13, c20, c21);
-	dq[2] = make_float4(c22, c30, c31, c40);
+	dq[0] = make_float4(qp[0], qp[1], qp[2], qp[3]);
+	dq[1] = make_float4(qp[4], qp[5], qp[6], qp[7]);
+	dq[2] = make_float4(qp[8], qp[9], qp[10], qp[11]);
 	dq[3] = make_float4(k3, 0.f, 0.f, 0.f);
 	if (out6) { out6[0] = ab_src[0]; out6[1] = ab_src[1]; }              // compact record: {recA, recB} travel with the coefficients (loaded late: fewer live registers)
 }
@@ -2513,16 +2462,19 @@ __device__ __forceinline__ FrWalkGeom fr_walk_geom(const FrWalkRec3& r, float pf
 	g.om1 = 1.f - g.alpha;
 	g.bi = __builtin_amdgcn_rcpf(g.om1);
 	g.cg = r.b4.w;
-	// u'^T Q u' + k3 as the bivariate polynomial of fr_fisher_record_one (terms of degree 2..4 in dx, dy), Horner in dx
-	const float A0 = r.q0.x + dy * (r.q0.y + dy * r.q0.z);
-	const float A1 = r.q0.w + dy * (r.q1.x + dy * r.q1.y);
-	const float A2 = r.q1.z + dy * (r.q1.w + dy * r.q2.x);
-	const float A3 = r.q2.y + dy * r.q2.z;
-	const float dy2 = dy * dy;
-	const float in3 = A3 + dx * r.q2.w;
-	const float in2 = A2 + dx * in3;
-	const float in1 = dy * A1 + dx * in2;
-	const float add = (r.a.z + dy2 * A0) + dx * in1;
+	// F(u) + k3 as the bivariate polynomial of fr_fisher_record_one (fr_scorer_poly_g; terms of degree 2..4), u = -conic d,
+	// Horner in ux over Horner in uy (fr_scorer_poly_eval's order)
+	const float ux = __builtin_fmaf(r.b4.x, dx, __builtin_fmaf(r.b4.x, dx, r.b4.y * dy));      // 2 hcx dx + ncy dy
+	const float uy = __builtin_fmaf(2.0f * r.b4.z, dy, r.b4.y * dx);                           // ncy dx + 2 hcz dy
+	const float A0 = r.q0.x + uy * (r.q0.y + uy * r.q0.z);
+	const float A1 = r.q0.w + uy * (r.q1.x + uy * r.q1.y);
+	const float A2 = r.q1.z + uy * (r.q1.w + uy * r.q2.x);
+	const float A3 = r.q2.y + uy * r.q2.z;
+	const float uy2 = uy * uy;
+	const float in3 = A3 + ux * r.q2.w;
+	const float in2 = A2 + ux * in3;
+	const float in1 = uy * A1 + ux * in2;
+	const float add = (r.a.z + uy2 * A0) + ux * in1;
 	g.add = (g.a_un * g.a_un) * add;                                       // S_i = (opacity G)^2 (u'^T Q u' + k3)
 	return g;
 }
@@ -3142,8 +3094,8 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 			const float dx = g.dx, dy = g.dy;
 			const float u0 = r.b4.x * dx + (r.b4.x * dx + r.b4.y * dy);
 			const float u1 = 2.0f * (r.b4.z * dy) + r.b4.y * dx;
-			const float u2 = dx * dx, u3 = dx * dy, u4 = dy * dy;
-			// record: {A'[0][0..3]} {A'[0][4], A'[1][0..2]} {A'[1][3..4], A'[2][0..1]} {A'[2][2..4], 1/opacity^2}
+			const float u2 = u0 * u0, u3 = u0 * u1, u4 = u1 * u1;               // gamma(u), u = -conic d (fr_math.h: fr_mean_rows_g)
+			// record: {R[0][0..3]} {R[0][4], R[1][0..2]} {R[1][3..4], R[2][0..1]} {R[2][2..4], 1/opacity^2}
 			const float l0 = r.q0.x * u0 + r.q0.y * u1 + r.q0.z * u2 + r.q0.w * u3 + r.q1.x * u4;
 			const float l1 = r.q1.y * u0 + r.q1.z * u1 + r.q1.w * u2 + r.q2.x * u3 + r.q2.y * u4;
 			const float l2 = r.q2.z * u0 + r.q2.w * u1 + r.q3.x * u2 + r.q3.y * u3 + r.q3.z * u4;

@@ -338,25 +338,19 @@ FR_HD fr_f3 fr_sh_to_rgb(int deg, fr_f3 pos, fr_f3 campos, const float* sh, uint
 // very same per-pixel leaf values as in the reference.
 // =====================================================================================================
 
-// backward.cu:335-407: (dL_dconic.x,.y,.w) -> dL_dcov3D[6] and the covariance part of dL_dmean
+// backward.cu:347-407, second half of computeCov2DCUDARelocated: (dL_da, dL_db, dL_dc) -- the gradient w.r.t. the three
+// entries of cov2D -- -> dL_dcov3D[6] and the covariance part of dL_dmean.  `nonzero`: the reference's `denom2inv != 0` branch.
 template <bool FAST = false>
-FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_fovx, float tan_fovy,
-                             const float* view, float dcx, float dcy, float dcw, fr_f3& dmean, float* dcov)
+FR_HD void fr_cov2d_abc_backward(const fr_cov2d& c, float h_x, float h_y, float tan_fovx, float tan_fovy,
+                                 const float* view, float dL_da, float dL_db, float dL_dc, bool nonzero, fr_f3& dmean, float* dcov)
 {
 	const float limx = 1.3f * tan_fovx;
 	const float limy = 1.3f * tan_fovy;
 	const float x_grad_mul = (c.txtz < -limx || c.txtz > limx) ? 0.f : 1.f;
 	const float y_grad_mul = (c.tytz < -limy || c.tytz > limy) ? 0.f : 1.f;
-	const float a = c.cov00 + 0.3f, b = c.cov01, cc = c.cov11 + 0.3f;
-	const float denom = a * cc - b * b;
-	float dL_da = 0, dL_db = 0, dL_dc = 0;
-	const float denom2inv = fr_divt<FAST>(1.0f, (denom * denom) + 0.0000001f);
 	const float* T0 = c.T0; const float* T1 = c.T1;
-	if (denom2inv != 0)
+	if (nonzero)
 	{
-		dL_da = denom2inv * (-cc * cc * dcx + 2 * b * cc * dcy + (denom - a * cc) * dcw);
-		dL_dc = denom2inv * (-a * a * dcw + 2 * a * b * dcy + (denom - a * cc) * dcx);
-		dL_db = denom2inv * 2 * (b * cc * dcx - (denom + 2 * b * b) * dcy + a * b * dcw);
 		dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
 		dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
 		dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
@@ -396,6 +390,24 @@ FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_
 	dmean.x = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;
 	dmean.y = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
 	dmean.z = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+}
+
+// backward.cu:335-407: (dL_dconic.x,.y,.w) -> dL_dcov3D[6] and the covariance part of dL_dmean
+template <bool FAST = false>
+FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_fovx, float tan_fovy,
+                             const float* view, float dcx, float dcy, float dcw, fr_f3& dmean, float* dcov)
+{
+	const float a = c.cov00 + 0.3f, b = c.cov01, cc = c.cov11 + 0.3f;
+	const float denom = a * cc - b * b;
+	float dL_da = 0, dL_db = 0, dL_dc = 0;
+	const float denom2inv = fr_divt<FAST>(1.0f, (denom * denom) + 0.0000001f);
+	if (denom2inv != 0)
+	{
+		dL_da = denom2inv * (-cc * cc * dcx + 2 * b * cc * dcy + (denom - a * cc) * dcw);
+		dL_dc = denom2inv * (-a * a * dcw + 2 * a * b * dcy + (denom - a * cc) * dcx);
+		dL_db = denom2inv * 2 * (b * cc * dcx - (denom + 2 * b * b) * dcy + a * b * dcw);
+	}
+	fr_cov2d_abc_backward<FAST>(c, h_x, h_y, tan_fovx, tan_fovy, view, dL_da, dL_db, dL_dc, denom2inv != 0, dmean, dcov);
 }
 
 // backward.cu:557-574: dL_dmean3D += Mp * (dL_dmean2D.x, dL_dmean2D.y); returns Mp as 3 rows of 2
@@ -489,6 +501,102 @@ FR_HD void fr_scale_rot_jacobian(fr_f3 scale, float mod, fr_f4 rot, const float 
 		Cm[0][j] = ds.x; Cm[1][j] = ds.y; Cm[2][j] = ds.z;
 		Cm[3][j] = dr.x; Cm[4][j] = dr.y; Cm[5][j] = dr.z; Cm[6][j] = dr.w;
 	}
+}
+
+// =====================================================================================================
+// The scorer's per-(view, Gaussian) records, in the basis g = conic * d  (d = mean2D - pixel).
+//
+// With w = opacity G dL_dalpha the reference's per-pair screen-space gradients are (backward.cu:1016-1031)
+//   dL_dmean2D = -w (W/2 gx, H/2 gy),        dL_dconic(x, y, w) = -w/2 (dx^2, dx dy, dy^2),
+// and its conic -> cov2D step (backward.cu:347-353) maps the latter to
+//   (dL_da, dL_db, dL_dc) = w f (gx^2 / 2, gx gy, gy^2 / 2),   f = denom^2 / (denom^2 + 1e-7),
+// exactly: -c^2 dx^2 + 2 b c dx dy - b^2 dy^2 = -(c dx - b dy)^2 = -(denom gx)^2, and likewise for the other two.  Every leaf
+// is therefore w times a row R_c applied to gamma = (gx, gy, gx^2, gx gy, gy^2).  The kernels evaluate that form: written
+// in (dx, dy) the same rows cancel like (cx dx + cy dy) does for a needle-shaped splat (condition number kappa =
+// |conic| |d| / |g|, up to the squared aspect ratio), and the H_inv-weighted sum of their SQUARES expanded into a polynomial
+// in (dx, dy) cancels like kappa^2 -- 2.4e-4 on the scores of the `border` test family, against 1e-6 for the binary32
+// reference chain itself (oracle/ arbiter build).  In g the rows have no structural cancellation.
+// The walk uses u = -g = (2 hcx dx + ncy dy, ncy dx + 2 hcz dy) with (hcx, ncy, hcz) = (-cx/2, -cy, -cz/2) of the record.
+// =====================================================================================================
+
+// Rg[r] = row of camera-frame mean component r over gamma(u) = (ux, uy, ux^2, ux uy, uy^2), u = -g;
+// Bg (optional) = d(dL_dcov3D[6]) / d(dL_da, dL_db, dL_dc) for fr_scale_rot_jacobian; cov2d_out: cov2D before the +0.3.
+template <bool FAST = false>
+FR_HD void fr_mean_rows_g(fr_f3 mean, const float* cov3D, const float* view, const float* proj,
+                          float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
+                          float Rg[3][5], float (*Bg)[3], float* cov2d_out, float* f_out)
+{
+	fr_cov2d c;
+	fr_cov2d_setup<FAST>(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c);
+	if (cov2d_out) { cov2d_out[0] = c.cov00; cov2d_out[1] = c.cov01; cov2d_out[2] = c.cov11; }
+	const float a = c.cov00 + 0.3f, b = c.cov01, cc = c.cov11 + 0.3f;
+	const float denom = a * cc - b * b;
+	const float d2 = denom * denom;
+	const float f = d2 < 3.0e38f ? fr_divt<FAST>(d2, d2 + 0.0000001f) : 0.f;     // denom^2 * denom2inv (backward.cu:337; 0 where denom2inv == 0)
+	if (f_out) *f_out = f;
+	float Mp[3][2];
+	fr_proj_jacobian<FAST>(mean, proj, Mp);
+	const float hw = (float)(0.5 * W), hh = (float)(0.5 * H);
+	// dL_dmean2D = -w (W/2 gx, H/2 gy) = w (W/2 ux, H/2 uy)
+	for (int k = 0; k < 3; k++) { Rg[k][0] = Mp[k][0] * hw; Rg[k][1] = Mp[k][1] * hh; }
+	// (dL_da, dL_db, dL_dc) = w f (ux^2 / 2, ux uy, uy^2 / 2)
+	const float wj[3] = { 0.5f * f, f, 0.5f * f };
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+	for (int j = 0; j < 3; j++)
+	{
+		fr_f3 dm; float dcov[6];
+		fr_cov2d_abc_backward<FAST>(c, focal_x, focal_y, tan_fovx, tan_fovy, view,
+		                            j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, true, dm, dcov);
+		Rg[0][2 + j] = dm.x * wj[j]; Rg[1][2 + j] = dm.y * wj[j]; Rg[2][2 + j] = dm.z * wj[j];
+		if (Bg)
+			for (int i = 0; i < 6; i++) Bg[i][j] = dcov[i] * wj[j];
+	}
+}
+
+// The 12 coefficients of F(u) = sum_c hv[c] (R_c . gamma(u))^2 as a bivariate polynomial in (ux, uy) (terms of degree 2, 3
+// and 4 only): Rg = the three mean rows, Cg = the seven scale / rotation rows over (ux^2, ux uy, uy^2) (C >= 11), hv = the
+// weights [mean 3 | opacity | scale 3 | rot 4].  Layout (what the walk's Horner scheme reads):
+//   q[0..11] = c02 c03 c04 c11 | c12 c13 c20 c21 | c22 c30 c31 c40      (cij multiplies ux^i uy^j)
+template <int C>
+FR_HD void fr_scorer_poly_g(const float Rg[3][5], const float (*Cg)[3], const float* hv, float q[12])
+{
+	// upper triangle of Q = sum_c hv[c] R_c^T R_c, off-diagonal entries doubled: (i, j) at 0 1 2 3 4 / 5 6 7 8 / 9 10 11 / 12 13 / 14
+	float qf[15];
+	int n = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+	for (int i = 0; i < 5; i++)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+		for (int j = i; j < 5; j++)
+		{
+			float acc = hv[0] * Rg[0][i] * Rg[0][j] + hv[1] * Rg[1][i] * Rg[1][j] + hv[2] * Rg[2][i] * Rg[2][j];
+			if (C >= 11 && i >= 2)
+			{
+				for (int r = 0; r < 7; r++) acc += hv[4 + r] * Cg[r][i - 2] * Cg[r][j - 2];
+			}
+			qf[n++] = (i == j) ? acc : 2.0f * acc;
+		}
+	q[0] = qf[5]; q[1] = qf[8]; q[2] = qf[14]; q[3] = qf[1];
+	q[4] = qf[4] + qf[7]; q[5] = qf[13]; q[6] = qf[0]; q[7] = qf[3] + qf[6];
+	q[8] = qf[11] + qf[12]; q[9] = qf[2]; q[10] = qf[10]; q[11] = qf[9];
+}
+
+// k3 + F(u): Horner in ux over Horner in uy, 14 operations (the order of evaluation the walk of k_fisher_tile_v3 uses)
+FR_HD float fr_scorer_poly_eval(const float q[12], float k3, float ux, float uy)
+{
+	const float A0 = q[0] + uy * (q[1] + uy * q[2]);
+	const float A1 = q[3] + uy * (q[4] + uy * q[5]);
+	const float A2 = q[6] + uy * (q[7] + uy * q[8]);
+	const float A3 = q[9] + uy * q[10];
+	const float in3 = A3 + ux * q[11];
+	const float in2 = A2 + ux * in3;
+	const float in1 = uy * A1 + ux * in2;
+	return (k3 + (uy * uy) * A0) + ux * in1;
 }
 
 // ---- SH backward, backward.cu:20-139 -----------------------------------------------------------------

@@ -54,10 +54,35 @@
 #define ORC_NUM_CHANNELS 3
 
 /* ---------------------------------------------------------------------- */
+/* `real`: the arithmetic type.  float = the oracle proper (liboracle.so).
+ * -DORC_DOUBLE builds the ARBITER (liboracle64.so): the same statements
+ * evaluated in binary64 on the same binary32 inputs and constants (a literal
+ * such as 0.3f stays the float constant, promoted), with every DECISION --
+ * culling, radii, tile rectangles, sort order, n_contrib, and the per-pair
+ * `power > 0` / `alpha < 1/255` tests -- taken from the binary32 run, so that
+ * both builds sum over identical contributor sets and their difference is
+ * the rounding error of the binary32 chain alone.  f32 = always binary32. */
+/* ---------------------------------------------------------------------- */
+typedef float f32;
+#ifdef ORC_DOUBLE
+typedef double real;
+#define R_SQRT sqrt
+#define R_MIN fmin
+#define R_MAX fmax
+#define R_CEIL ceil
+#else
+typedef float real;
+#define R_SQRT sqrtf
+#define R_MIN fminf
+#define R_MAX fmaxf
+#define R_CEIL ceilf
+#endif
+
+/* ---------------------------------------------------------------------- */
 /* deterministic helpers                                                   */
 /* ---------------------------------------------------------------------- */
 
-static inline int orc_f2i(float f)
+static inline int orc_f2i(real f)
 {
 	if (f != f) return 0;
 	if (f >= 2147483648.0f) return INT_MAX;
@@ -65,40 +90,58 @@ static inline int orc_f2i(float f)
 	return (int)f;
 }
 
-static inline float orc_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-static inline uint32_t orc_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline f32 orc_bits2f(uint32_t u) { f32 f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orc_f2bits(f32 f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 /* 2^k for k in [-126, 127] */
-static inline float orc_pow2i(int k) { return orc_bits2f((uint32_t)(k + 127) << 23); }
+static inline f32 orc_pow2i(int k) { return orc_bits2f((uint32_t)(k + 127) << 23); }
 
-float orc_expf(float x)
+f32 orc_expf(f32 x)
 {
 	if (x != x) return x;
 	if (x > 88.72283905206835f) return INFINITY;
 	if (x < -103.97208f) return 0.0f;
-	float kf = rintf(x * 1.44269504088896341f);
-	float r = fmaf(kf, -0.693359375f, x);
+	f32 kf = rintf(x * 1.44269504088896341f);
+	f32 r = fmaf(kf, -0.693359375f, x);
 	r = fmaf(kf, 2.12194440e-4f, r);
-	float p = 1.9875691500e-4f;
+	f32 p = 1.9875691500e-4f;
 	p = fmaf(p, r, 1.3981999507e-3f);
 	p = fmaf(p, r, 8.3334519073e-3f);
 	p = fmaf(p, r, 4.1665795894e-2f);
 	p = fmaf(p, r, 1.6666665459e-1f);
 	p = fmaf(p, r, 5.0000001201e-1f);
-	float r2 = r * r;
-	float y = fmaf(p, r2, r) + 1.0f;
+	f32 r2 = r * r;
+	f32 y = fmaf(p, r2, r) + 1.0f;
 	int k = (int)kf;
 	int k1 = k >> 1;          /* floor(k/2) */
 	int k2 = k - k1;
 	return (y * orc_pow2i(k1)) * orc_pow2i(k2);
 }
 
-/* --- GLM restatement --------------------------------------------------- */
-typedef struct { float x, y, z; } v3;
-typedef struct { float x, y, z, w; } v4;
-typedef struct { float m[3][3]; } m3; /* m[col][row] */
+#ifdef ORC_DOUBLE
+static inline real orc_exp(real x) { return exp(x); }
+#else
+static inline real orc_exp(real x) { return orc_expf(x); }
+#endif
 
-static inline m3 m3_cols(float a, float b, float c, float d, float e, float f, float g, float h, float i)
+/* The per-pair contributor tests of forward.cu:338-351 / backward.cu:985-996, ALWAYS in binary32 on the binary32
+ * projection outputs (xy2 = means2D, co4 = conic_opacity of the float build): nonzero = the pair is skipped. */
+static inline int orc_pair_skipped(const f32* xy2, const f32* co4, f32 pixfx, f32 pixfy)
+{
+	f32 dx = xy2[0] - pixfx, dy = xy2[1] - pixfy;
+	f32 power = -0.5f * (co4[0] * dx * dx + co4[2] * dy * dy) - co4[1] * dx * dy;
+	if (power > 0.0f)
+		return 1;
+	f32 alpha = fminf(0.99f, co4[3] * orc_expf(power));
+	return alpha < 1.0f / 255.0f;
+}
+
+/* --- GLM restatement --------------------------------------------------- */
+typedef struct { real x, y, z; } v3;
+typedef struct { real x, y, z, w; } v4;
+typedef struct { real m[3][3]; } m3; /* m[col][row] */
+
+static inline m3 m3_cols(real a, real b, real c, real d, real e, real f, real g, real h, real i)
 {
 	m3 r;
 	r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c;
@@ -122,7 +165,7 @@ static inline m3 m3_transpose(m3 a)
 			r.m[c][rr] = a.m[rr][c];
 	return r;
 }
-static inline m3 m3_scale(float s, m3 a)
+static inline m3 m3_scale(real s, m3 a)
 {
 	m3 r;
 	for (int c = 0; c < 3; c++)
@@ -130,32 +173,32 @@ static inline m3 m3_scale(float s, m3 a)
 			r.m[c][rr] = a.m[c][rr] * s;
 	return r;
 }
-static inline float v3_dot(v3 a, v3 b)
+static inline real v3_dot(v3 a, v3 b)
 {
-	float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+	real tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
 	return tx + ty + tz;
 }
 static inline v3 m3_col(m3 a, int c) { v3 r = { a.m[c][0], a.m[c][1], a.m[c][2] }; return r; }
 
 /* --- auxiliary.h ------------------------------------------------------- */
-static const float SH_C0 = 0.28209479177387814f;
-static const float SH_C1 = 0.4886025119029199f;
-static const float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+static const real SH_C0 = 0.28209479177387814f;
+static const real SH_C1 = 0.4886025119029199f;
+static const real SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
 	-1.0925484305920792f, 0.5462742152960396f };
-static const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+static const real SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
 	0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
 
 /* auxiliary.h:41-44 : double-precision literals -> evaluated in double */
-static inline float orc_ndc2pix(float v, int S)
+static inline real orc_ndc2pix(real v, int S)
 {
-	return (float)(((v + 1.0) * S - 1.0) * 0.5);
+	return (real)(((v + 1.0) * S - 1.0) * 0.5);
 }
 
 static inline uint32_t orc_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 static inline int orc_imax(int a, int b) { return a > b ? a : b; }
 
 /* auxiliary.h:46-56 */
-static inline void orc_get_rect(float px, float py, int max_radius, uint32_t gx, uint32_t gy,
+static inline void orc_get_rect(real px, real py, int max_radius, uint32_t gx, uint32_t gy,
 	uint32_t* minx, uint32_t* miny, uint32_t* maxx, uint32_t* maxy)
 {
 	*minx = orc_umin(gx, (uint32_t)orc_imax(0, orc_f2i((px - max_radius) / ORC_BLOCK_X)));
@@ -165,7 +208,7 @@ static inline void orc_get_rect(float px, float py, int max_radius, uint32_t gx,
 }
 
 /* auxiliary.h:58-77,89-97 */
-static inline v3 orc_tp4x3(v3 p, const float* m)
+static inline v3 orc_tp4x3(v3 p, const real* m)
 {
 	v3 t = {
 		m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
@@ -173,7 +216,7 @@ static inline v3 orc_tp4x3(v3 p, const float* m)
 		m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] };
 	return t;
 }
-static inline v4 orc_tp4x4(v3 p, const float* m)
+static inline v4 orc_tp4x4(v3 p, const real* m)
 {
 	v4 t = {
 		m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
@@ -182,7 +225,7 @@ static inline v4 orc_tp4x4(v3 p, const float* m)
 		m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] };
 	return t;
 }
-static inline v3 orc_tv4x3T(v3 p, const float* m)
+static inline v3 orc_tv4x3T(v3 p, const real* m)
 {
 	v3 t = {
 		m[0] * p.x + m[1] * p.y + m[2] * p.z,
@@ -193,8 +236,8 @@ static inline v3 orc_tv4x3T(v3 p, const float* m)
 /* auxiliary.h:107-117 */
 static inline v3 orc_dnormvdv(v3 v, v3 dv)
 {
-	float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-	float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+	real sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+	real invsum32 = 1.0f / R_SQRT(sum2 * sum2 * sum2);
 	v3 r;
 	r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
 	r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
@@ -202,7 +245,7 @@ static inline v3 orc_dnormvdv(v3 v, v3 dv)
 	return r;
 }
 /* auxiliary.h:139-164 (prefiltered trap not modelled: returns -1 instead) */
-static inline int orc_in_frustum(v3 p_orig, const float* viewmatrix, v3* p_view)
+static inline int orc_in_frustum(v3 p_orig, const real* viewmatrix, v3* p_view)
 {
 	*p_view = orc_tp4x3(p_orig, viewmatrix);
 	if (p_view->z <= 0.001f)
@@ -233,28 +276,28 @@ uint32_t orc_get_higher_msb(uint32_t n)
 /* ---------------------------------------------------------------------- */
 
 /* forward.cu:20-71 ; means/shs are the full arrays, idx selects */
-static v3 orc_color_from_sh(int idx, int deg, int max_coeffs, const float* means, v3 campos,
-	const float* shs, uint8_t* clamped)
+static v3 orc_color_from_sh(int idx, int deg, int max_coeffs, const real* means, v3 campos,
+	const real* shs, uint8_t* clamped)
 {
 	v3 pos = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
 	v3 dir = { pos.x - campos.x, pos.y - campos.y, pos.z - campos.z };
-	float len = sqrtf(v3_dot(dir, dir));
+	real len = R_SQRT(v3_dot(dir, dir));
 	dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
 
-	const float* sh = shs + 3 * (size_t)idx * max_coeffs; /* sh[k] = (sh[3k], sh[3k+1], sh[3k+2]) */
-	float res[3];
-	float x = dir.x, y = dir.y, z = dir.z;
+	const real* sh = shs + 3 * (size_t)idx * max_coeffs; /* sh[k] = (sh[3k], sh[3k+1], sh[3k+2]) */
+	real res[3];
+	real x = dir.x, y = dir.y, z = dir.z;
 	for (int c = 0; c < 3; c++)
 	{
 #define SH(k) sh[3 * (k) + c]
-		float result = SH_C0 * SH(0);
+		real result = SH_C0 * SH(0);
 		if (deg > 0)
 		{
 			result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
 			if (deg > 1)
 			{
-				float xx = x * x, yy = y * y, zz = z * z;
-				float xy = x * y, yz = y * z, xz = x * z;
+				real xx = x * x, yy = y * y, zz = z * z;
+				real xy = x * y, yz = y * z, xz = x * z;
 				result = result +
 					SH_C2[0] * xy * SH(4) +
 					SH_C2[1] * yz * SH(5) +
@@ -281,27 +324,27 @@ static v3 orc_color_from_sh(int idx, int deg, int max_coeffs, const float* means
 	clamped[3 * idx + 0] = (res[0] < 0);
 	clamped[3 * idx + 1] = (res[1] < 0);
 	clamped[3 * idx + 2] = (res[2] < 0);
-	v3 out = { fmaxf(res[0], 0.0f), fmaxf(res[1], 0.0f), fmaxf(res[2], 0.0f) };
+	v3 out = { R_MAX(res[0], 0.0f), R_MAX(res[1], 0.0f), R_MAX(res[2], 0.0f) };
 	return out;
 }
 
 /* shared by forward.cu:74-113 and backward.cu:300-333 */
 typedef struct {
 	v3 t;                 /* clamped camera-space mean */
-	float txtz, tytz;
+	real txtz, tytz;
 	m3 J, W, T, Vrk, cov; /* GLM-convention matrices, cov BEFORE the +0.3 */
 } cov2d_ctx;
 
-static void orc_cov2d_common(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
-	const float* cov3D, const float* viewmatrix, cov2d_ctx* c)
+static void orc_cov2d_common(v3 mean, real focal_x, real focal_y, real tan_fovx, real tan_fovy,
+	const real* cov3D, const real* viewmatrix, cov2d_ctx* c)
 {
 	v3 t = orc_tp4x3(mean, viewmatrix);
-	const float limx = 1.3f * tan_fovx;
-	const float limy = 1.3f * tan_fovy;
+	const real limx = 1.3f * tan_fovx;
+	const real limy = 1.3f * tan_fovy;
 	c->txtz = t.x / t.z;
 	c->tytz = t.y / t.z;
-	t.x = fminf(limx, fmaxf(-limx, c->txtz)) * t.z;
-	t.y = fminf(limy, fmaxf(-limy, c->tytz)) * t.z;
+	t.x = R_MIN(limx, R_MAX(-limx, c->txtz)) * t.z;
+	t.y = R_MIN(limy, R_MAX(-limy, c->tytz)) * t.z;
 	c->t = t;
 	c->J = m3_cols(
 		focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z),
@@ -322,7 +365,7 @@ static void orc_cov2d_common(v3 mean, float focal_x, float focal_y, float tan_fo
 /* shared by forward.cu:118-152 and backward.cu:415-434 */
 static m3 orc_quat_R(v4 rot)
 {
-	float r = rot.x, x = rot.y, y = rot.z, z = rot.w; /* NOT normalised (forward.cu:127) */
+	real r = rot.x, x = rot.y, y = rot.z, z = rot.w; /* NOT normalised (forward.cu:127) */
 	return m3_cols(
 		1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
 		2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
@@ -330,7 +373,7 @@ static m3 orc_quat_R(v4 rot)
 }
 static m3 orc_identity(void) { return m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1); }
 
-void orc_cov3d(const float* scale, float mod, const float* rot4, float* cov3D)
+void orc_cov3d(const real* scale, real mod, const real* rot4, real* cov3D)
 {
 	m3 S = orc_identity();
 	S.m[0][0] = mod * scale[0];
@@ -351,32 +394,36 @@ void orc_cov3d(const float* scale, float mod, const float* rot4, float* cov3D)
 /* forward.cu:155-256.  Outputs for culled Gaussians are left untouched except
  * radii/tiles_touched = 0 (the reference leaves them uninitialised). */
 void orc_preprocess(int P, int D, int M,
-	const float* means3D, const float* scales, float scale_modifier, const float* rotations,
-	const float* opacities, const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-	const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-	int W, int H, float tan_fovx, float tan_fovy,
-	int32_t* radii, float* means2D, float* depths, float* cov3Ds, float* rgb,
-	float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped)
+	const real* means3D, const real* scales, real scale_modifier, const real* rotations,
+	const real* opacities, const real* shs, const real* cov3D_precomp, const real* colors_precomp,
+	const real* viewmatrix, const real* projmatrix, const real* cam_pos,
+	int W, int H, real tan_fovx, real tan_fovy,
+	int32_t* radii, real* means2D, real* depths, real* cov3Ds, real* rgb,
+	real* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped, const int32_t* radii_fixed)
 {
-	const float focal_y = H / (2.0f * tan_fovy);   /* rasterizer_impl.cu:222-223 */
-	const float focal_x = W / (2.0f * tan_fovx);
+	/* radii_fixed (arbiter build only; NULL otherwise): the radii of the binary32 run.  A Gaussian that run culled is
+	 * culled here, one it kept is kept with that radius; tiles_touched is not produced (binning is the float run's). */
+	const real focal_y = H / (2.0f * tan_fovy);   /* rasterizer_impl.cu:222-223 */
+	const real focal_x = W / (2.0f * tan_fovx);
 	const uint32_t gx = (W + ORC_BLOCK_X - 1) / ORC_BLOCK_X, gy = (H + ORC_BLOCK_Y - 1) / ORC_BLOCK_Y;
 
 	for (int idx = 0; idx < P; idx++)
 	{
 		radii[idx] = 0;
 		tiles_touched[idx] = 0;
+		if (radii_fixed && radii_fixed[idx] <= 0)
+			continue;
 
 		v3 p_orig = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
 		v3 p_view;
-		if (!orc_in_frustum(p_orig, viewmatrix, &p_view))
+		if (!orc_in_frustum(p_orig, viewmatrix, &p_view) && !radii_fixed)
 			continue;
 
 		v4 p_hom = orc_tp4x4(p_orig, projmatrix);
-		float p_w = 1.0f / (p_hom.w + 0.0000001f);
+		real p_w = 1.0f / (p_hom.w + 0.0000001f);
 		v3 p_proj = { p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w };
 
-		const float* cov3D;
+		const real* cov3D;
 		if (cov3D_precomp != NULL)
 			cov3D = cov3D_precomp + (size_t)idx * 6;
 		else
@@ -389,22 +436,22 @@ void orc_preprocess(int P, int D, int M,
 		orc_cov2d_common(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &cc);
 		cc.cov.m[0][0] += 0.3f;
 		cc.cov.m[1][1] += 0.3f;
-		float covx = cc.cov.m[0][0], covy = cc.cov.m[0][1], covz = cc.cov.m[1][1];
+		real covx = cc.cov.m[0][0], covy = cc.cov.m[0][1], covz = cc.cov.m[1][1];
 
-		float det = (covx * covz - covy * covy);
+		real det = (covx * covz - covy * covy);
 		if (det == 0.0f)
 			continue;
-		float det_inv = 1.f / det;
-		float conx = covz * det_inv, cony = -covy * det_inv, conz = covx * det_inv;
+		real det_inv = 1.f / det;
+		real conx = covz * det_inv, cony = -covy * det_inv, conz = covx * det_inv;
 
-		float mid = 0.5f * (covx + covz);
-		float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-		float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-		float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-		float pix_x = orc_ndc2pix(p_proj.x, W), pix_y = orc_ndc2pix(p_proj.y, H);
+		real mid = 0.5f * (covx + covz);
+		real lambda1 = mid + R_SQRT(R_MAX(0.1f, mid * mid - det));
+		real lambda2 = mid - R_SQRT(R_MAX(0.1f, mid * mid - det));
+		real my_radius = R_CEIL(3.f * R_SQRT(R_MAX(lambda1, lambda2)));
+		real pix_x = orc_ndc2pix(p_proj.x, W), pix_y = orc_ndc2pix(p_proj.y, H);
 		uint32_t minx, miny, maxx, maxy;
 		orc_get_rect(pix_x, pix_y, orc_f2i(my_radius), gx, gy, &minx, &miny, &maxx, &maxy);
-		if ((maxx - minx) * (maxy - miny) == 0)
+		if ((maxx - minx) * (maxy - miny) == 0 && !radii_fixed)
 			continue;
 
 		if (colors_precomp == NULL)
@@ -417,7 +464,7 @@ void orc_preprocess(int P, int D, int M,
 		}
 
 		depths[idx] = p_view.z;
-		radii[idx] = orc_f2i(my_radius);
+		radii[idx] = radii_fixed ? radii_fixed[idx] : orc_f2i(my_radius);
 		means2D[2 * idx] = pix_x;
 		means2D[2 * idx + 1] = pix_y;
 		conic_opacity[4 * idx + 0] = conx;
@@ -428,8 +475,9 @@ void orc_preprocess(int P, int D, int M,
 	}
 }
 
+#ifndef ORC_DOUBLE   /* visibility, binning and sort are decisions: the float build's */
 /* rasterizer_impl.cu:54-66 */
-void orc_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
+void orc_mark_visible(int P, const real* means3D, const real* viewmatrix, const real* projmatrix, uint8_t* present)
 {
 	(void)projmatrix;
 	for (int idx = 0; idx < P; idx++)
@@ -477,7 +525,7 @@ static void orc_radix_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_
 
 /* Returns num_rendered.  If point_list == NULL only counts.
  * keys_sorted[R], point_list[R], ranges[2*tiles] (x,y interleaved). */
-int64_t orc_bin(int P, const float* means2D, const float* depths, const int32_t* radii,
+int64_t orc_bin(int P, const real* means2D, const real* depths, const int32_t* radii,
 	const uint32_t* tiles_touched, int W, int H,
 	uint64_t* keys_sorted, uint32_t* point_list, uint32_t* ranges)
 {
@@ -539,13 +587,19 @@ int64_t orc_bin(int P, const float* means2D, const float* depths, const int32_t*
 	return R;
 }
 
+#endif /* !ORC_DOUBLE */
+
 /* ---------------------------------------------------------------------- */
 /* forward render: forward.cu:261-393                                      */
 /* ---------------------------------------------------------------------- */
 void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
-	const float* means2D, const float* features, const float* conic_opacity, const float* depths,
-	const float* bg_color, float* final_T, uint32_t* n_contrib, float* out_color, float* out_depth)
+	const real* means2D, const real* features, const real* conic_opacity, const real* depths,
+	const real* bg_color, real* final_T, uint32_t* n_contrib, real* out_color, real* out_depth,
+	const f32* dec_means2D, const f32* dec_conic_opacity, const uint32_t* dec_n_contrib)
 {
+	/* dec_* (arbiter build only; NULL otherwise): means2D / conic_opacity / n_contrib of the binary32 run.  With them a
+	 * pixel composites exactly the float run's contributors: its per-pair tests and its last contributor (the median
+	 * depth, which no Fisher quantity reads, is still chosen by this build's own transmittance). */
 	const uint32_t gx = (W + ORC_BLOCK_X - 1) / ORC_BLOCK_X, gy = (H + ORC_BLOCK_Y - 1) / ORC_BLOCK_Y;
 	for (uint32_t ty = 0; ty < gy; ty++)
 	for (uint32_t tx = 0; tx < gx; tx++)
@@ -558,27 +612,34 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
 			if (!(pxx < (uint32_t)W && pxy < (uint32_t)H))
 				continue;
 			uint32_t pix_id = W * pxy + pxx;
-			float pixfx = (float)pxx, pixfy = (float)pxy;
+			real pixfx = (real)pxx, pixfy = (real)pxy;
 
-			float T = 1.0f;
+			real T = 1.0f;
 			uint32_t contributor = 0, last_contributor = 0;
-			float C[ORC_NUM_CHANNELS] = { 0 };
-			float D = 15.0f;  /* median depth default (forward.cu:308) */
+			real C[ORC_NUM_CHANNELS] = { 0 };
+			real D = 15.0f;  /* median depth default (forward.cu:308) */
 
 			for (uint32_t k = r0; k < r1; k++)
 			{
 				contributor++;
 				uint32_t id = point_list[k];
-				float dx = means2D[2 * id] - pixfx, dy = means2D[2 * id + 1] - pixfy;
-				const float* con_o = conic_opacity + 4 * (size_t)id;
-				float power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
-				if (power > 0.0f)
+				real dx = means2D[2 * id] - pixfx, dy = means2D[2 * id + 1] - pixfy;
+				const real* con_o = conic_opacity + 4 * (size_t)id;
+				real power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+				if (dec_means2D)
+				{
+					if (contributor > dec_n_contrib[pix_id])
+						break;
+					if (orc_pair_skipped(dec_means2D + 2 * (size_t)id, dec_conic_opacity + 4 * (size_t)id, (f32)pxx, (f32)pxy))
+						continue;
+				}
+				else if (power > 0.0f)
 					continue;
-				float alpha = fminf(0.99f, con_o[3] * orc_expf(power));
-				if (alpha < 1.0f / 255.0f)
+				real alpha = R_MIN(0.99f, con_o[3] * orc_exp(power));
+				if (!dec_means2D && alpha < 1.0f / 255.0f)
 					continue;
-				float test_T = T * (1 - alpha);
-				if (test_T < 0.0001f)
+				real test_T = T * (1 - alpha);
+				if (!dec_means2D && test_T < 0.0001f)
 					break; /* done = true */
 				for (int ch = 0; ch < ORC_NUM_CHANNELS; ch++)
 					C[ch] += features[id * ORC_NUM_CHANNELS + ch] * alpha * T;
@@ -600,38 +661,38 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
 /* backward                                                                */
 /* ---------------------------------------------------------------------- */
 
-static inline double orc_pow(float x, int power)
+static inline double orc_pow(real x, int power)
 {
 	if (power == 1) return (double)x;
 	if (power == 2) return (double)(x * x);
-	return (double)powf(x, (float)power);
+	return (double)powf((f32)x, (f32)power);
 }
 
 /* backward.cu:276-408 with idx == 0 on relocated pointers */
-static void orc_cov2d_backward(v3 mean, int radius, const float* cov3D, float h_x, float h_y,
-	float tan_fovx, float tan_fovy, const float* view_matrix, const float* dL_dconics /*float4*/,
-	v3* dL_dmeans, float* dL_dcov /*6*/)
+static void orc_cov2d_backward(v3 mean, int radius, const real* cov3D, real h_x, real h_y,
+	real tan_fovx, real tan_fovy, const real* view_matrix, const real* dL_dconics /*float4*/,
+	v3* dL_dmeans, real* dL_dcov /*6*/)
 {
 	if (!(radius > 0))
 		return;
 	v3 dL_dconic = { dL_dconics[0], dL_dconics[1], dL_dconics[3] };
 	cov2d_ctx cc;
 	orc_cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view_matrix, &cc);
-	const float limx = 1.3f * tan_fovx;
-	const float limy = 1.3f * tan_fovy;
-	const float x_grad_mul = cc.txtz < -limx || cc.txtz > limx ? 0 : 1;
-	const float y_grad_mul = cc.tytz < -limy || cc.tytz > limy ? 0 : 1;
+	const real limx = 1.3f * tan_fovx;
+	const real limy = 1.3f * tan_fovy;
+	const real x_grad_mul = cc.txtz < -limx || cc.txtz > limx ? 0 : 1;
+	const real y_grad_mul = cc.tytz < -limy || cc.tytz > limy ? 0 : 1;
 	v3 t = cc.t;
 #define T_(i,j) cc.T.m[i][j]
 #define W_(i,j) cc.W.m[i][j]
 #define V_(i,j) cc.Vrk.m[i][j]
-	float a = cc.cov.m[0][0] += 0.3f;
-	float b = cc.cov.m[0][1];
-	float c = cc.cov.m[1][1] += 0.3f;
+	real a = cc.cov.m[0][0] += 0.3f;
+	real b = cc.cov.m[0][1];
+	real c = cc.cov.m[1][1] += 0.3f;
 
-	float denom = a * c - b * b;
-	float dL_da = 0, dL_db = 0, dL_dc = 0;
-	float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+	real denom = a * c - b * b;
+	real dL_da = 0, dL_db = 0, dL_dc = 0;
+	real denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
 
 	if (denom2inv != 0)
 	{
@@ -653,44 +714,44 @@ static void orc_cov2d_backward(v3 mean, int radius, const float* cov3D, float h_
 			dL_dcov[i] = 0;
 	}
 
-	float dL_dT00 = 2 * (T_(0,0) * V_(0,0) + T_(0,1) * V_(0,1) + T_(0,2) * V_(0,2)) * dL_da +
+	real dL_dT00 = 2 * (T_(0,0) * V_(0,0) + T_(0,1) * V_(0,1) + T_(0,2) * V_(0,2)) * dL_da +
 		(T_(1,0) * V_(0,0) + T_(1,1) * V_(0,1) + T_(1,2) * V_(0,2)) * dL_db;
-	float dL_dT01 = 2 * (T_(0,0) * V_(1,0) + T_(0,1) * V_(1,1) + T_(0,2) * V_(1,2)) * dL_da +
+	real dL_dT01 = 2 * (T_(0,0) * V_(1,0) + T_(0,1) * V_(1,1) + T_(0,2) * V_(1,2)) * dL_da +
 		(T_(1,0) * V_(1,0) + T_(1,1) * V_(1,1) + T_(1,2) * V_(1,2)) * dL_db;
-	float dL_dT02 = 2 * (T_(0,0) * V_(2,0) + T_(0,1) * V_(2,1) + T_(0,2) * V_(2,2)) * dL_da +
+	real dL_dT02 = 2 * (T_(0,0) * V_(2,0) + T_(0,1) * V_(2,1) + T_(0,2) * V_(2,2)) * dL_da +
 		(T_(1,0) * V_(2,0) + T_(1,1) * V_(2,1) + T_(1,2) * V_(2,2)) * dL_db;
-	float dL_dT10 = 2 * (T_(1,0) * V_(0,0) + T_(1,1) * V_(0,1) + T_(1,2) * V_(0,2)) * dL_dc +
+	real dL_dT10 = 2 * (T_(1,0) * V_(0,0) + T_(1,1) * V_(0,1) + T_(1,2) * V_(0,2)) * dL_dc +
 		(T_(0,0) * V_(0,0) + T_(0,1) * V_(0,1) + T_(0,2) * V_(0,2)) * dL_db;
-	float dL_dT11 = 2 * (T_(1,0) * V_(1,0) + T_(1,1) * V_(1,1) + T_(1,2) * V_(1,2)) * dL_dc +
+	real dL_dT11 = 2 * (T_(1,0) * V_(1,0) + T_(1,1) * V_(1,1) + T_(1,2) * V_(1,2)) * dL_dc +
 		(T_(0,0) * V_(1,0) + T_(0,1) * V_(1,1) + T_(0,2) * V_(1,2)) * dL_db;
-	float dL_dT12 = 2 * (T_(1,0) * V_(2,0) + T_(1,1) * V_(2,1) + T_(1,2) * V_(2,2)) * dL_dc +
+	real dL_dT12 = 2 * (T_(1,0) * V_(2,0) + T_(1,1) * V_(2,1) + T_(1,2) * V_(2,2)) * dL_dc +
 		(T_(0,0) * V_(2,0) + T_(0,1) * V_(2,1) + T_(0,2) * V_(2,2)) * dL_db;
 
-	float dL_dJ00 = W_(0,0) * dL_dT00 + W_(0,1) * dL_dT01 + W_(0,2) * dL_dT02;
-	float dL_dJ02 = W_(2,0) * dL_dT00 + W_(2,1) * dL_dT01 + W_(2,2) * dL_dT02;
-	float dL_dJ11 = W_(1,0) * dL_dT10 + W_(1,1) * dL_dT11 + W_(1,2) * dL_dT12;
-	float dL_dJ12 = W_(2,0) * dL_dT10 + W_(2,1) * dL_dT11 + W_(2,2) * dL_dT12;
+	real dL_dJ00 = W_(0,0) * dL_dT00 + W_(0,1) * dL_dT01 + W_(0,2) * dL_dT02;
+	real dL_dJ02 = W_(2,0) * dL_dT00 + W_(2,1) * dL_dT01 + W_(2,2) * dL_dT02;
+	real dL_dJ11 = W_(1,0) * dL_dT10 + W_(1,1) * dL_dT11 + W_(1,2) * dL_dT12;
+	real dL_dJ12 = W_(2,0) * dL_dT10 + W_(2,1) * dL_dT11 + W_(2,2) * dL_dT12;
 #undef T_
 #undef W_
 #undef V_
-	float tz = 1.f / t.z;
-	float tz2 = tz * tz;
-	float tz3 = tz2 * tz;
+	real tz = 1.f / t.z;
+	real tz2 = tz * tz;
+	real tz3 = tz2 * tz;
 
-	float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-	float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-	float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+	real dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+	real dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+	real dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
 
 	v3 dt = { dL_dtx, dL_dty, dL_dtz };
 	*dL_dmeans = orc_tv4x3T(dt, view_matrix); /* ASSIGN (backward.cu:407) */
 }
 
 /* backward.cu:412-475 */
-static void orc_cov3d_backward(const float* scale, float mod, const float* rot4, const float* dL_dcov3D,
+static void orc_cov3d_backward(const real* scale, real mod, const real* rot4, const real* dL_dcov3D,
 	v3* dL_dscale, v4* dL_drot)
 {
 	v4 q = { rot4[0], rot4[1], rot4[2], rot4[3] };
-	float r = q.x, x = q.y, y = q.z, z = q.w;
+	real r = q.x, x = q.y, y = q.z, z = q.w;
 	m3 R = orc_quat_R(q);
 	m3 S = orc_identity();
 	v3 s = { mod * scale[0], mod * scale[1], mod * scale[2] };
@@ -724,32 +785,32 @@ static void orc_cov3d_backward(const float* scale, float mod, const float* rot4,
 }
 
 /* backward.cu:20-139 with idx == 0 on relocated pointers.
- * sh : float pointer as passed by the fused kernel (shs + M*global_id, backward.cu:1067 -- a float
+ * sh : real pointer as passed by the fused kernel (shs + M*global_id, backward.cu:1067 -- a real
  *      offset, not a vec3 offset; reproduced as is), read as vec3 sh[k] = sh[3k..3k+2].
  * dL_dsh : local scratch of 16 vec3. */
-static void orc_sh_backward(int deg, v3 pos, v3 campos, const float* sh, const uint8_t* clamped,
-	const float* dL_dcolor3, v3* dL_dmeans, float* dL_dsh /*16*3*/)
+static void orc_sh_backward(int deg, v3 pos, v3 campos, const real* sh, const uint8_t* clamped,
+	const real* dL_dcolor3, v3* dL_dmeans, real* dL_dsh /*16*3*/)
 {
 	v3 dir_orig = { pos.x - campos.x, pos.y - campos.y, pos.z - campos.z };
-	float len = sqrtf(v3_dot(dir_orig, dir_orig));
+	real len = R_SQRT(v3_dot(dir_orig, dir_orig));
 	v3 dir = { dir_orig.x / len, dir_orig.y / len, dir_orig.z / len };
 
-	float dL_dRGB[3] = { dL_dcolor3[0], dL_dcolor3[1], dL_dcolor3[2] };
+	real dL_dRGB[3] = { dL_dcolor3[0], dL_dcolor3[1], dL_dcolor3[2] };
 	dL_dRGB[0] *= clamped[0] ? 0 : 1;
 	dL_dRGB[1] *= clamped[1] ? 0 : 1;
 	dL_dRGB[2] *= clamped[2] ? 0 : 1;
 
-	float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
-	float x = dir.x, y = dir.y, z = dir.z;
+	real dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+	real x = dir.x, y = dir.y, z = dir.z;
 #define SHV(k, c) sh[3 * (k) + (c)]
 #define SET(k, coef) for (int c_ = 0; c_ < 3; c_++) dL_dsh[3 * (k) + c_] = (coef) * dL_dRGB[c_]
-	float dRGBdsh0 = SH_C0;
+	real dRGBdsh0 = SH_C0;
 	SET(0, dRGBdsh0);
 	if (deg > 0)
 	{
-		float dRGBdsh1 = -SH_C1 * y;
-		float dRGBdsh2 = SH_C1 * z;
-		float dRGBdsh3 = -SH_C1 * x;
+		real dRGBdsh1 = -SH_C1 * y;
+		real dRGBdsh2 = SH_C1 * z;
+		real dRGBdsh3 = -SH_C1 * x;
 		SET(1, dRGBdsh1);
 		SET(2, dRGBdsh2);
 		SET(3, dRGBdsh3);
@@ -761,13 +822,13 @@ static void orc_sh_backward(int deg, v3 pos, v3 campos, const float* sh, const u
 		}
 		if (deg > 1)
 		{
-			float xx = x * x, yy = y * y, zz = z * z;
-			float xy = x * y, yz = y * z, xz = x * z;
-			float dRGBdsh4 = SH_C2[0] * xy;
-			float dRGBdsh5 = SH_C2[1] * yz;
-			float dRGBdsh6 = SH_C2[2] * (2.f * zz - xx - yy);
-			float dRGBdsh7 = SH_C2[3] * xz;
-			float dRGBdsh8 = SH_C2[4] * (xx - yy);
+			real xx = x * x, yy = y * y, zz = z * z;
+			real xy = x * y, yz = y * z, xz = x * z;
+			real dRGBdsh4 = SH_C2[0] * xy;
+			real dRGBdsh5 = SH_C2[1] * yz;
+			real dRGBdsh6 = SH_C2[2] * (2.f * zz - xx - yy);
+			real dRGBdsh7 = SH_C2[3] * xz;
+			real dRGBdsh8 = SH_C2[4] * (xx - yy);
 			SET(4, dRGBdsh4);
 			SET(5, dRGBdsh5);
 			SET(6, dRGBdsh6);
@@ -781,13 +842,13 @@ static void orc_sh_backward(int deg, v3 pos, v3 campos, const float* sh, const u
 			}
 			if (deg > 2)
 			{
-				float dRGBdsh9 = SH_C3[0] * y * (3.f * xx - yy);
-				float dRGBdsh10 = SH_C3[1] * xy * z;
-				float dRGBdsh11 = SH_C3[2] * y * (4.f * zz - xx - yy);
-				float dRGBdsh12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-				float dRGBdsh13 = SH_C3[4] * x * (4.f * zz - xx - yy);
-				float dRGBdsh14 = SH_C3[5] * z * (xx - yy);
-				float dRGBdsh15 = SH_C3[6] * x * (xx - 3.f * yy);
+				real dRGBdsh9 = SH_C3[0] * y * (3.f * xx - yy);
+				real dRGBdsh10 = SH_C3[1] * xy * z;
+				real dRGBdsh11 = SH_C3[2] * y * (4.f * zz - xx - yy);
+				real dRGBdsh12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+				real dRGBdsh13 = SH_C3[4] * x * (4.f * zz - xx - yy);
+				real dRGBdsh14 = SH_C3[5] * z * (xx - yy);
+				real dRGBdsh15 = SH_C3[6] * x * (xx - 3.f * yy);
 				SET(9, dRGBdsh9);
 				SET(10, dRGBdsh10);
 				SET(11, dRGBdsh11);
@@ -834,23 +895,65 @@ static void orc_sh_backward(int deg, v3 pos, v3 campos, const float* sh, const u
 	dL_dmeans->z += dL_dmean.z;
 }
 
+/* The leaf gradients of ONE (pixel, Gaussian) pair as renderCUDAFused forms them (backward.cu:1016-1090), for a given
+ * w = opacity * G * dL_dalpha and d = mean2D - pixel: out[11] = [mean xyz | opacity | scale xyz | rot rxyz].  Tests of the
+ * kernels' per-Gaussian record algebra use it (binary32: the reference's own rounding; arbiter build: the exact value). */
+void orc_pair_leaves(const real* mean3, const real* cov3D, const real* scale, real mod, const real* rot4,
+	const real* viewmatrix, const real* projmatrix, int W, int H, real tan_fovx, real tan_fovy,
+	const real* con_o, real dx, real dy, real w, real* out)
+{
+	const real focal_y = H / (2.0f * tan_fovy);
+	const real focal_x = W / (2.0f * tan_fovx);
+	const real ddelx_dx = (real)(0.5 * W);
+	const real ddely_dy = (real)(0.5 * H);
+	/* gdx * dL_dG = G dx * opacity dL_dalpha = w dx */
+	const real wdx = w * dx, wdy = w * dy;
+	real cur_dL_dmean2D[2], cur_dL_dconic2D[4] = { 0, 0, 0, 0 };
+	cur_dL_dmean2D[0] = (-wdx * con_o[0] - wdy * con_o[1]) * ddelx_dx;
+	cur_dL_dmean2D[1] = (-wdy * con_o[2] - wdx * con_o[1]) * ddely_dy;
+	cur_dL_dconic2D[0] = -0.5f * wdx * dx;
+	cur_dL_dconic2D[1] = -0.5f * wdx * dy;
+	cur_dL_dconic2D[3] = -0.5f * wdy * dy;
+	v3 mean = { mean3[0], mean3[1], mean3[2] };
+	v3 cur_dL_dmeans = { 0.0f, 0.0f, 0.0f };
+	real cur_dL_dcov3D[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+	orc_cov2d_backward(mean, 1, cov3D, focal_x, focal_y, tan_fovx, tan_fovy, viewmatrix, cur_dL_dconic2D, &cur_dL_dmeans, cur_dL_dcov3D);
+	const real* proj = projmatrix;
+	v4 m_hom = orc_tp4x4(mean, proj);
+	real m_w = 1.0f / (m_hom.w + 0.0000001f);
+	real mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+	real mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+	cur_dL_dmeans.x += (proj[0] * m_w - proj[3] * mul1) * cur_dL_dmean2D[0] + (proj[1] * m_w - proj[3] * mul2) * cur_dL_dmean2D[1];
+	cur_dL_dmeans.y += (proj[4] * m_w - proj[7] * mul1) * cur_dL_dmean2D[0] + (proj[5] * m_w - proj[7] * mul2) * cur_dL_dmean2D[1];
+	cur_dL_dmeans.z += (proj[8] * m_w - proj[11] * mul1) * cur_dL_dmean2D[0] + (proj[9] * m_w - proj[11] * mul2) * cur_dL_dmean2D[1];
+	v3 cur_dL_dscale = { 0.0f, 0.0f, 0.0f };
+	v4 cur_dL_drot = { 0.0f, 0.0f, 0.0f, 0.0f };
+	orc_cov3d_backward(scale, mod, rot4, cur_dL_dcov3D, &cur_dL_dscale, &cur_dL_drot);
+	out[0] = cur_dL_dmeans.x; out[1] = cur_dL_dmeans.y; out[2] = cur_dL_dmeans.z;
+	out[3] = w / con_o[3];
+	out[4] = cur_dL_dscale.x; out[5] = cur_dL_dscale.y; out[6] = cur_dL_dscale.z;
+	out[7] = cur_dL_drot.x; out[8] = cur_dL_drot.y; out[9] = cur_dL_drot.z; out[10] = cur_dL_drot.w;
+}
+
 /* renderCUDAFused, backward.cu:850-1140.
- * Outputs (float, caller allocated, overwritten): dL_dmean2D[P*3] (z stays 0), dL_dconic[P*4],
+ * Outputs (real, caller allocated, overwritten): dL_dmean2D[P*3] (z stays 0), dL_dconic[P*4],
  * dL_dopacity[P], dL_dcolors[P*3], dL_dmean3D[P*3], dL_dcov3D[P*6], dL_dsh[P*M*3], dL_dscale[P*3],
  * dL_drot[P*4].  pair_count (optional) receives the number of contributing pairs. */
 void orc_render_backward_fused(int P, int D, int M, int W, int H,
 	const uint32_t* ranges, const uint32_t* point_list,
-	const float* bg_color, const float* means2D, const float* conic_opacity, const float* colors,
-	const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
-	const float* means3D, const int32_t* radii, const float* shs, const uint8_t* clamped,
-	const float* scales, const float* rotations, float scale_modifier, const float* cov3Ds,
-	const float* viewmatrix, const float* projmatrix, float tan_fovx, float tan_fovy, const float* campos,
+	const real* bg_color, const real* means2D, const real* conic_opacity, const real* colors,
+	const real* final_Ts, const uint32_t* n_contrib, const real* dL_dpixels,
+	const real* means3D, const int32_t* radii, const real* shs, const uint8_t* clamped,
+	const real* scales, const real* rotations, real scale_modifier, const real* cov3Ds,
+	const real* viewmatrix, const real* projmatrix, real tan_fovx, real tan_fovy, const real* campos,
 	int grad_power,
-	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmean3D,
-	float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int64_t* pair_count)
+	real* dL_dmean2D, real* dL_dconic, real* dL_dopacity, real* dL_dcolors, real* dL_dmean3D,
+	real* dL_dcov3D, real* dL_dsh, real* dL_dscale, real* dL_drot, int64_t* pair_count,
+	const f32* dec_means2D, const f32* dec_conic_opacity)
 {
-	const float focal_y = H / (2.0f * tan_fovy);  /* rasterizer_impl.cu:383-384 */
-	const float focal_x = W / (2.0f * tan_fovx);
+	/* dec_* (arbiter build only; NULL otherwise): the binary32 run's means2D / conic_opacity, for the per-pair tests */
+	const real focal_y = H / (2.0f * tan_fovy);  /* rasterizer_impl.cu:383-384 */
+	const real focal_x = W / (2.0f * tan_fovx);
 	const uint32_t gx = (W + ORC_BLOCK_X - 1) / ORC_BLOCK_X, gy = (H + ORC_BLOCK_Y - 1) / ORC_BLOCK_Y;
 	const int C = ORC_NUM_CHANNELS;
 	size_t Ps = (size_t)(P > 0 ? P : 1);
@@ -865,8 +968,8 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
 	double* a_rot = (double*)calloc(Ps * 4, sizeof(double));
 	int64_t pairs = 0;
 
-	const float ddelx_dx = (float)(0.5 * W);
-	const float ddely_dy = (float)(0.5 * H);
+	const real ddelx_dx = (real)(0.5 * W);
+	const real ddely_dy = (real)(0.5 * H);
 	const v3 campos_v = { campos ? campos[0] : 0.f, campos ? campos[1] : 0.f, campos ? campos[2] : 0.f };
 
 	for (uint32_t ty = 0; ty < gy; ty++)
@@ -880,18 +983,18 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
 			if (!(pxx < (uint32_t)W && pxy < (uint32_t)H))
 				continue;
 			uint32_t pix_id = W * pxy + pxx;
-			float pixfx = (float)pxx, pixfy = (float)pxy;
+			real pixfx = (real)pxx, pixfy = (real)pxy;
 
-			const float T_final = final_Ts[pix_id];
-			float T = T_final;
+			const real T_final = final_Ts[pix_id];
+			real T = T_final;
 			uint32_t contributor = r1 - r0;
 			const int last_contributor = (int)n_contrib[pix_id];
-			float accum_rec[3] = { 0 };
-			float dL_dpixel[3];
+			real accum_rec[3] = { 0 };
+			real dL_dpixel[3];
 			for (int i = 0; i < C; i++)
 				dL_dpixel[i] = dL_dpixels[i * H * W + pix_id];
-			float last_alpha = 0;
-			float last_color[3] = { 0 };
+			real last_alpha = 0;
+			real last_color[3] = { 0 };
 
 			for (uint32_t kk = r1; kk > r0; kk--)
 			{
@@ -899,47 +1002,52 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
 				if (contributor >= (uint32_t)last_contributor) /* unsigned compare as in the reference */
 					continue;
 				const int global_id = (int)point_list[kk - 1];
-				const float dx = means2D[2 * global_id] - pixfx, dy = means2D[2 * global_id + 1] - pixfy;
-				const float* con_o = conic_opacity + 4 * (size_t)global_id;
-				const float power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
-				if (power > 0.0f)
+				const real dx = means2D[2 * global_id] - pixfx, dy = means2D[2 * global_id + 1] - pixfy;
+				const real* con_o = conic_opacity + 4 * (size_t)global_id;
+				const real power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+				if (dec_means2D)
+				{
+					if (orc_pair_skipped(dec_means2D + 2 * (size_t)global_id, dec_conic_opacity + 4 * (size_t)global_id, (f32)pxx, (f32)pxy))
+						continue;
+				}
+				else if (power > 0.0f)
 					continue;
-				const float G = orc_expf(power);
-				const float alpha = fminf(0.99f, con_o[3] * G);
-				if (alpha < 1.0f / 255.0f)
+				const real G = orc_exp(power);
+				const real alpha = R_MIN(0.99f, con_o[3] * G);
+				if (!dec_means2D && alpha < 1.0f / 255.0f)
 					continue;
 
 				T = T / (1.f - alpha);
-				const float dchannel_dcolor = alpha * T;
+				const real dchannel_dcolor = alpha * T;
 
-				float cur_dL_dcolors[3] = { 0, 0, 0 };
-				float cur_dL_dmean2D[3] = { 0, 0, 0 };
-				float cur_dL_dconic2D[4] = { 0, 0, 0, 0 };
-				float cur_dL_dopacity = 0.0f;
+				real cur_dL_dcolors[3] = { 0, 0, 0 };
+				real cur_dL_dmean2D[3] = { 0, 0, 0 };
+				real cur_dL_dconic2D[4] = { 0, 0, 0, 0 };
+				real cur_dL_dopacity = 0.0f;
 
-				float dL_dalpha = 0.0f;
+				real dL_dalpha = 0.0f;
 				for (int ch = 0; ch < C; ch++)
 				{
-					const float c = colors[global_id * C + ch];
+					const real c = colors[global_id * C + ch];
 					accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
 					last_color[ch] = c;
-					const float dL_dchannel = dL_dpixel[ch];
+					const real dL_dchannel = dL_dpixel[ch];
 					dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
 					cur_dL_dcolors[ch] = dchannel_dcolor * dL_dchannel;
 				}
 				dL_dalpha *= T;
 				last_alpha = alpha;
 
-				float bg_dot_dpixel = 0;
+				real bg_dot_dpixel = 0;
 				for (int i = 0; i < C; i++)
 					bg_dot_dpixel += bg_color[i] * dL_dpixel[i];
 				dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
 
-				const float dL_dG = con_o[3] * dL_dalpha;
-				const float gdx = G * dx;
-				const float gdy = G * dy;
-				const float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
-				const float dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
+				const real dL_dG = con_o[3] * dL_dalpha;
+				const real gdx = G * dx;
+				const real gdy = G * dy;
+				const real dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
+				const real dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
 
 				cur_dL_dmean2D[0] = dL_dG * dG_ddelx * ddelx_dx;
 				cur_dL_dmean2D[1] = dL_dG * dG_ddely * ddely_dy;
@@ -953,13 +1061,13 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
 					continue;
 
 				v3 cur_dL_dmeans = { 0.0f, 0.0f, 0.0f };
-				float cur_dL_dcov3D[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+				real cur_dL_dcov3D[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
 				v3 mean = { means3D[3 * global_id], means3D[3 * global_id + 1], means3D[3 * global_id + 2] };
 				orc_cov2d_backward(mean, radii[global_id], cov3Ds + 6 * (size_t)global_id, focal_x, focal_y,
 					tan_fovx, tan_fovy, viewmatrix, cur_dL_dconic2D, &cur_dL_dmeans, cur_dL_dcov3D);
 
 				const int num_shs = (1 + D) * (1 + D);
-				float cur_dL_dshs[16 * 3];
+				real cur_dL_dshs[16 * 3];
 				memset(cur_dL_dshs, 0, sizeof(cur_dL_dshs));
 				v3 cur_dL_dscale = { 0.0f, 0.0f, 0.0f };
 				v4 cur_dL_drot = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -968,11 +1076,11 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
 				if (radii[global_id] > 0)
 				{
 					v3 m = mean;
-					const float* proj = projmatrix;
+					const real* proj = projmatrix;
 					v4 m_hom = orc_tp4x4(m, proj);
-					float m_w = 1.0f / (m_hom.w + 0.0000001f);
-					float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
-					float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+					real m_w = 1.0f / (m_hom.w + 0.0000001f);
+					real mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+					real mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
 					v3 dL_dmean;
 					dL_dmean.x = (proj[0] * m_w - proj[3] * mul1) * cur_dL_dmean2D[0] + (proj[1] * m_w - proj[3] * mul2) * cur_dL_dmean2D[1];
 					dL_dmean.y = (proj[4] * m_w - proj[7] * mul1) * cur_dL_dmean2D[0] + (proj[5] * m_w - proj[7] * mul2) * cur_dL_dmean2D[1];
@@ -1022,16 +1130,16 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
 
 	for (int i = 0; i < P; i++)
 	{
-		dL_dmean2D[3 * i + 0] = (float)a_m2[2 * i]; dL_dmean2D[3 * i + 1] = (float)a_m2[2 * i + 1]; dL_dmean2D[3 * i + 2] = 0.f;
-		dL_dconic[4 * i + 0] = (float)a_con[3 * i]; dL_dconic[4 * i + 1] = (float)a_con[3 * i + 1];
-		dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = (float)a_con[3 * i + 2];
-		dL_dopacity[i] = (float)a_op[i];
-		for (int k = 0; k < 3; k++) dL_dcolors[3 * i + k] = (float)a_col[3 * i + k];
-		for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = (float)a_m3[3 * i + k];
-		for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = (float)a_cov[6 * i + k];
-		for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)i * M * 3 + k] = (float)a_sh[(size_t)i * M * 3 + k];
-		for (int k = 0; k < 3; k++) dL_dscale[3 * i + k] = (float)a_sc[3 * i + k];
-		for (int k = 0; k < 4; k++) dL_drot[4 * i + k] = (float)a_rot[4 * i + k];
+		dL_dmean2D[3 * i + 0] = (real)a_m2[2 * i]; dL_dmean2D[3 * i + 1] = (real)a_m2[2 * i + 1]; dL_dmean2D[3 * i + 2] = 0.f;
+		dL_dconic[4 * i + 0] = (real)a_con[3 * i]; dL_dconic[4 * i + 1] = (real)a_con[3 * i + 1];
+		dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = (real)a_con[3 * i + 2];
+		dL_dopacity[i] = (real)a_op[i];
+		for (int k = 0; k < 3; k++) dL_dcolors[3 * i + k] = (real)a_col[3 * i + k];
+		for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = (real)a_m3[3 * i + k];
+		for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = (real)a_cov[6 * i + k];
+		for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)i * M * 3 + k] = (real)a_sh[(size_t)i * M * 3 + k];
+		for (int k = 0; k < 3; k++) dL_dscale[3 * i + k] = (real)a_sc[3 * i + k];
+		for (int k = 0; k < 4; k++) dL_drot[4 * i + k] = (real)a_rot[4 * i + k];
 	}
 	if (pair_count) *pair_count = pairs;
 	free(a_m2); free(a_con); free(a_op); free(a_col); free(a_m3); free(a_cov); free(a_sh); free(a_sc); free(a_rot);
@@ -1042,20 +1150,22 @@ void orc_render_backward_fused(int P, int D, int M, int W, int H,
  * mean of the squared distances to the 3 nearest OTHER points (self excluded by index).
  * Brute force O(P^2); parity unpinned (no reference source, call site or fixture). */
 /* ---------------------------------------------------------------------- */
-void orc_knn_dist2(int P, const float* pts, float* out)
+#ifndef ORC_DOUBLE
+void orc_knn_dist2(int P, const real* pts, real* out)
 {
 	for (int i = 0; i < P; i++)
 	{
-		float best[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f };
-		float rx = pts[3 * i], ry = pts[3 * i + 1], rz = pts[3 * i + 2];
+		real best[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f };
+		real rx = pts[3 * i], ry = pts[3 * i + 1], rz = pts[3 * i + 2];
 		for (int j = 0; j < P; j++)
 		{
 			if (j == i) continue;
-			float dx = pts[3 * j] - rx, dy = pts[3 * j + 1] - ry, dz = pts[3 * j + 2] - rz;
-			float dist = dx * dx + dy * dy + dz * dz;
+			real dx = pts[3 * j] - rx, dy = pts[3 * j + 1] - ry, dz = pts[3 * j + 2] - rz;
+			real dist = dx * dx + dy * dy + dz * dz;
 			for (int k = 0; k < 3; k++)
-				if (best[k] > dist) { float t = best[k]; best[k] = dist; dist = t; }
+				if (best[k] > dist) { real t = best[k]; best[k] = dist; dist = t; }
 		}
 		out[i] = (best[0] + best[1] + best[2]) / 3.0f;
 	}
 }
+#endif

@@ -3,12 +3,14 @@ Fisher columns) on the adversarial scene families of test_gpu_rasterizer_parity.
 are not multiples of 16, one tile with thousands of splats, depth ties, alpha saturating at 0.99 with T < 1e-4 kills --
 and on a scene built to SIT ON the thresholds of forward.cu:347-363 (alpha within 1e-6 of 1/255, T within rounding of
 1e-4, power == 0), against the oracle's compute_Hessian / pose_eval (gaussian.py:1338-1375, 1503-1570;
-gaussian_object.py:1940-2045).  Tolerance (north star): 1e-4 relative on the scores and on cur_H."""
+gaussian_object.py:1940-2045).  Tolerance (north star): 1e-4 relative on the scores -- every family, no exception -- and on the
+entries of cur_H; an entry's tolerance is widened only by a multiple of what the reference's OWN binary32 chain loses on that
+Gaussian, measured against the arbiter (the oracle's statements in binary64 on the same contributor sets, oracle/ref.py;
+tests/test_arbiter_cpu.py): needle-shaped and near-plane splats, where the reference itself is off by up to several per cent."""
 import numpy as np
 import pytest
 import torch
 
-from gpu_util import assert_close
 from scenes import random_scene, intrinsics, rel_err
 from test_gpu_rasterizer_parity import _scene, CASES
 
@@ -121,11 +123,25 @@ def family(gpu, oracle):
             args = (sc["means3D"], sc["colors"], sc["rotations"], sc["opacities"], sc["scales"])
             t = [torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in args]
             scorers = {C: FisherScorer(cam, *t, columns=C) for C in (4, 11)}
-            cur = {C: [oracle.compute_hessian(ocam, w, *args, columns=C) for w in w2cs] for C in (4, 11)}
-            z_cam = [oracle.transform_points(w, sc["means3D"])[:, 2] for w in w2cs]
-            cache[case] = dict(P=sc["means3D"].shape[0], w2cs=w2cs, args=args, scorers=scorers, cur=cur, ocam=ocam, z_cam=z_cam)
+            # (cur_H of the oracle, cur_H of the arbiter, vis_count) per view
+            cur = {C: [oracle.compute_hessian(ocam, w, *args, columns=C, arbiter=True) for w in w2cs] for C in (4, 11)}
+            cache[case] = dict(P=sc["means3D"].shape[0], w2cs=w2cs, args=args, scorers=scorers, cur=cur, ocam=ocam)
         return cache[case]
     return get
+
+
+# multiple of the reference chain's own binary32 deviation (per Gaussian) by which an entry's tolerance is widened.  Measured need
+# (tools/arbiter_diag.py): 0.9 for the record kernels (k_fisher_tile_v3h, u = -conic d basis), 5.1 for the two-pass kernel of the
+# 11-column / gradient-image modes (k_fisher_tile_v2: the reference's own (dx, dy) chain with a different rounding sequence).
+K_DEV = {4: 2.0, 11: 8.0}
+
+
+def _entry_tolerance(o, a, C):
+    """[P, C] tolerance: (1e-4 + K r_G) |o| + 1e-7 max|o|, r_G = the largest relative deviation of the binary32 oracle `o` from the
+    arbiter `a` over the Gaussian's columns (entries below 1e-7 of the largest are not rated)."""
+    o64, big = o.astype(np.float64), np.abs(a) > 1e-7 * np.abs(a).max()
+    r = np.where(big, np.abs(o64 - a) / np.maximum(np.abs(a), 1e-300), 0.0).max(axis=1, keepdims=True)
+    return (1e-4 + K_DEV[C] * r) * np.abs(o64) + 1e-7 * np.abs(o64).max(), r
 
 
 @pytest.mark.parametrize("columns", [4, 11])
@@ -135,8 +151,9 @@ def test_scorer_modes_on_adversarial_families(family, gpu, case, columns):
     P, V, C = f["P"], len(f["w2cs"]), columns
     sc = f["scorers"][C]
     w2c = torch.from_numpy(f["w2cs"]).to(gpu)
-    cur_o = np.stack([h for h, _ in f["cur"][C]])                       # [V, P, C]
-    vis_o = np.array([v for _, v in f["cur"][C]])
+    cur_o = np.stack([h for h, _, _ in f["cur"][C]])                    # [V, P, C] binary32 oracle
+    cur_a = np.stack([h for _, h, _ in f["cur"][C]])                    # ... and the arbiter
+    vis_o = np.array([v for _, _, v in f["cur"][C]])
     # keyframes = views 1.. (so that H_train differs from the view being scored), reg 0.1 as gaussian.py:1367
     H_train_o = cur_o[1:].sum(0, dtype=np.float32)
     H_inv_o = (np.float32(1.0) / (H_train_o + np.float32(0.1))).astype(np.float32)
@@ -146,46 +163,35 @@ def test_scorer_modes_on_adversarial_families(family, gpu, case, columns):
     cur = torch.zeros((V, P, C), device=gpu)
     r = sc.run(w2c, out_H=cur, out_H_per_view=True)
     assert np.array_equal(r["vis_count"].cpu().numpy(), vis_o)
+    tols = []
+    n_wide = 0
     for v in range(V):
-        # Splats closer than 0.2 (kept by this fork, culled upstream: auxiliary.h:154) have Jacobians of order focal / z and an
-        # ill-conditioned cov2D chain: one ulp on such a splat's depth moves the ORACLE's own entry by 1e-4 (measured on
-        # `general`, Gaussian 15762: 1.09e-4), so their entries are held to 1e-3; everything else to 1e-4.
-        z = f["z_cam"][v]
-        near = (z > 0) & (z < 0.2)
-        if case == "border":                # aspect ratios up to 150 and |q|^4 up to 6.5: the cov2D chain is as ill-conditioned there
-            near = np.ones_like(near)
-        got = cur[v].cpu().numpy()
-        assert_close(got[~near], cur_o[v][~near], 1e-4, f"{case} cur_H[{v}]", atol_frac=1e-7)
-        if near.any():
-            # (`border` is about WHICH splats are listed -- vis_count above, the scores below; its needle-shaped splats are held
-            # to 1e-3 with a floor of 1e-5 of the largest entry)
-            assert_close(got[near], cur_o[v][near], 1e-3, f"{case} cur_H[{v}] near-plane", atol_frac=1e-5 if case == "border" else 1e-7)
+        tol, r_G = _entry_tolerance(cur_o[v], cur_a[v], C)
+        tols.append(tol)
+        n_wide += int((r_G > 2e-5).sum())
+        got = cur[v].cpu().numpy().astype(np.float64)
+        bad = np.abs(got - cur_o[v]) > tol
+        assert not bad.any(), (case, v, int(bad.sum()), float((np.abs(got - cur_o[v]) / np.maximum(tol, 1e-300)).max()))
+    # the widening is the exception: a few per cent of the Gaussians at most, on the families built to provoke it
+    assert n_wide <= (0.05 if case in ("border", "general") else 0.002) * V * P, (case, n_wide)
     Ht = torch.zeros((P, C), device=gpu)
     sc.run(w2c[1:], out_H=Ht)
-    near_any = np.any([(z > 0) & (z < 0.2) for z in f["z_cam"][1:]], axis=0)
-    if case == "border":
-        near_any = np.ones_like(near_any)
-    assert_close(Ht.cpu().numpy()[~near_any], H_train_o[~near_any], 1e-4, f"{case} H_train", atol_frac=1e-7)
-    assert_close(Ht.cpu().numpy()[near_any], H_train_o[near_any], 1e-3, f"{case} H_train near-plane", atol_frac=1e-5 if case == "border" else 1e-7)
+    bad = np.abs(Ht.cpu().numpy().astype(np.float64) - H_train_o) > np.sum(tols[1:], axis=0)
+    assert not bad.any(), (case, "H_train", int(bad.sum()))
 
-    # `border`: needle-shaped splats (aspect ratios up to 150, cov3D scaled by |q|^4) make the conic's determinant a difference
-    # of nearly equal products; the two kernel generations, which evaluate the same chain with different instruction sequences,
-    # sit 1.6e-4 and 4.9e-4 from the oracle there (and agree with each other no better), so that family is held to 1e-3 --
-    # what it is for is the exact set of listed splats (vis_count), with and without the early frustum test.
-    stol = 1e-3 if case == "border" else 1e-4
-    # score-only (the single-pass kernel), H_inv shared by the views
+    # score-only (the single-pass kernel), H_inv shared by the views: 1e-4 on every family
     H_inv = torch.from_numpy(H_inv_o).to(gpu)
     s = sc.run(w2c, H_inv=H_inv)
     assert np.array_equal(s["vis_count"].cpu().numpy(), vis_o)
-    assert rel_err(s["scores"].cpu().numpy(), want) < stol, (case, s["scores"].cpu().numpy(), want)
+    assert rel_err(s["scores"].cpu().numpy(), want) < 1e-4, (case, s["scores"].cpu().numpy(), want)
 
     # per-view H_inv (the path evaluator's mode)
     g = torch.Generator().manual_seed(5)
     Hv = (torch.rand((V, P, C), generator=g) * 3.0 + 0.05)
     want_pv = (cur_o.astype(np.float64) * Hv.numpy().astype(np.float64)).sum(axis=(1, 2))
     s_pv = sc.run(w2c, H_inv=Hv.to(gpu), H_inv_per_view=True)
-    assert rel_err(s_pv["scores"].cpu().numpy(), want_pv) < stol, (case, s_pv["scores"].cpu().numpy(), want_pv)
+    assert rel_err(s_pv["scores"].cpu().numpy(), want_pv) < 1e-4, (case, s_pv["scores"].cpu().numpy(), want_pv)
 
     # scores and materialised cur_H of the SAME launch sequence agree (gaussian.py:1367)
     s2 = (cur.double() * H_inv.double()[None]).sum(dim=(1, 2)).cpu().numpy()
-    assert rel_err(s["scores"].cpu().numpy(), s2) < stol
+    assert rel_err(s["scores"].cpu().numpy(), s2) < 1e-4
