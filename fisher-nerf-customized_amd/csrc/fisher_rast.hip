@@ -47,6 +47,7 @@
 #define FR_SORT_SMALL_KEYS 2048      // per-tile segments up to this size: 16 KiB of LDS, many workgroups per CU
 #define FR_SORT_MID_KEYS 4096        // listed segments up to this size: 32 KiB of LDS, 256 threads
 #define FR_SORT_BIG_KEYS 16384       // up to this size: 128 KiB of LDS, one workgroup per CU; beyond: global memory
+#define FR_VC_MAX 16                 // most views one k_preprocess_views workgroup takes (its per-view LDS counters; fr_pick_VC clamps to it)
 #define FR_BATCH 256                 // splats staged per round in the forward pass
 #define FR_BWD_BATCH 128             // splats staged per round in the backward passes
 
@@ -535,8 +536,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	uint32_t* s_pf = s_bm + VC * W32;
 	const bool compact = RC != 0 && ra.comp != nullptr;
 	__shared__ uint32_t s_np;
-	__shared__ uint32_t s_n[16];
-	__shared__ uint32_t s_ref[16];               // tile instances by the reference's rule (radius rectangle), per view
+	__shared__ uint32_t s_n[FR_VC_MAX];
+	__shared__ uint32_t s_ref[FR_VC_MAX];        // tile instances by the reference's rule (radius rectangle), per view
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int v0 = blockIdx.y * VC;
 	const int nv = min(VC, p.V - v0);
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	for (int t = tid; t < nv * p.T; t += FR_THREADS) hist[t] = 0;
 	const bool has_w2c = p.w2c != nullptr;
 	if (has_w2c) for (int t = tid; t < nv * 12; t += FR_THREADS) s_wm[t] = p.w2c[16 * (size_t)(v0 + t / 12) + (t % 12)];
-	if (tid < 16) { s_n[tid] = 0; s_ref[tid] = 0; }
+	if (tid < FR_VC_MAX) { s_n[tid] = 0; s_ref[tid] = 0; }
 	if (tid == 0) s_np = 0;
 	if (compact) for (int t = tid; t < nv * W32; t += FR_THREADS) s_bm[t] = 0u;
 	float vm[16], pm[16];
@@ -3923,6 +3924,7 @@ static inline int fr_pick_VC(long long T)
 	static int forced = -1;                                   // FR_VC=<n>: A/B runs
 	if (forced < 0) { const char* e = getenv("FR_VC"); forced = e ? atoi(e) : 0; }
 	long long vc = 8192 / (T < 1 ? 1 : T);
+	if (vc > FR_VC_MAX) vc = FR_VC_MAX;                       // the kernel's per-view counters (s_n / s_ref) hold FR_VC_MAX views
 	if (forced > 0) return (int)(forced > vc ? (vc < 1 ? 1 : vc) : forced);
 	if (vc > 4) vc = 4;                                       // 4 views per workgroup: 2.16 ms per step against 2.20 for 8 and 2.19 for 2
 	return (int)(vc < 1 ? 1 : (vc > 8 ? 8 : vc));
@@ -4093,6 +4095,27 @@ static FrSideStream& fr_side_stream(int which = 0)
 	return ss;
 }
 
+// Every fork onto a side stream is joined back into the caller's stream on EVERY way out of fr_bin_pipeline, the error returns
+// included: the caller may free or reuse the workspace as soon as its own stream has drained, and a side-stream kernel that is
+// still writing records or keys into it must therefore be ordered in front of whatever the caller enqueues next.
+struct FrJoinGuard {
+	hipStream_t s; FrSideStream* side[2] = { nullptr, nullptr }; int n = 0;
+	explicit FrJoinGuard(hipStream_t caller) : s(caller) {}
+	void forked(FrSideStream* ss) { side[n++] = ss; }
+	int join()                                   // normal path: returns FR_OK or the error
+	{
+		int rc = FR_OK;
+		for (int i = 0; i < n; i++)
+		{
+			if (hipEventRecord(side[i]->join, side[i]->stream) != hipSuccess || hipStreamWaitEvent(s, side[i]->join, 0) != hipSuccess)
+				rc = fr_fail(FR_ELAUNCH, "side stream join failed");
+		}
+		n = 0;
+		return rc;
+	}
+	~FrJoinGuard() { if (n) { char keep[sizeof(g_err)]; memcpy(keep, g_err, sizeof(keep)); (void)join(); memcpy(g_err, keep, sizeof(keep)); } }   // error path: keep the first message
+};
+
 // Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
 // k_preprocess_views; with the single-view front end, k_fisher_records after k_scatter_keys, beside the sorts, on the second side stream).
 struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; };     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
@@ -4132,7 +4155,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		else hipLaunchKernelGGL((k_pack_static<11>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float*)plan->ra.cov_trace);
 		if ((rc = fr_check_launch("k_pack_static"))) return rc;
 	}
-	FrSideStream* side2 = nullptr;
+	FrJoinGuard joins(s);
 	if (multi)
 	{
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
@@ -4168,12 +4191,8 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		if (plan->form_a) hipLaunchKernelGGL((k_fisher_records<4, false, true>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
 		else if (plan->columns == 4) hipLaunchKernelGGL((k_fisher_records<4, false, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
 		else hipLaunchKernelGGL((k_fisher_records<11, false, false>), gridP, dim3(FR_THREADS), 0, rs, p, plan->ra);
+		if (forked2) joins.forked(&s2);
 		if ((rc = fr_check_launch("k_fisher_records"))) return rc;
-		if (forked2)
-		{
-			if (hipEventRecord(s2.join, s2.stream) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipEventRecord(join 2) failed");
-			side2 = &s2;
-		}
 	}
 	// The three sort tiers touch disjoint tile segments.  The 1024-thread tier has few, long-running workgroups (one per
 	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
@@ -4182,17 +4201,15 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	const bool want_fork = fr_debug_mode() != 7 && (!multi || p.V >= 8);   // FR_DEBUG_MODE=7: every sort tier on the caller's stream (timing ablation)
 	const bool forked = want_fork && side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
 	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
+	if (forked) joins.forked(&side);
 	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
-	if (forked && hipEventRecord(side.join, side.stream) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipEventRecord(join) failed");
 	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
 	const int mid_blocks = p.T * p.V < 2048 ? p.T * p.V : 2048;
 	hipLaunchKernelGGL(k_sort_mid_tiles, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_mid_tiles"))) return rc;
-	if (forked && hipStreamWaitEvent(s, side.join, 0) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipStreamWaitEvent(join) failed");
-	if (side2 && hipStreamWaitEvent(s, side2->join, 0) != hipSuccess) return fr_fail(FR_ELAUNCH, "hipStreamWaitEvent(join 2) failed");
-	return FR_OK;
+	return joins.join();
 }
 
 static void fr_carve_single(FrParams& p, const FrLayout& L, char* geom, char* bin, char* img)

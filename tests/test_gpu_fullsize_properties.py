@@ -1,5 +1,11 @@
-"""-m gpu: BASELINE.json's full size (500k Gaussians, 64 candidate 256x256 views) is too big for the scalar oracle, so
-parity there rests on size-independent properties of the path, plus one oracle view as an anchor."""
+"""-m gpu: BASELINE.json's full size (500k Gaussians, 64 candidate 256x256 views): size-independent properties of the path,
+one oracle view compared entry by entry, and ALL 64 scores of configs[1] against the oracle's pose_eval (H_train from the 16
+keyframes included), the scalar oracle running in one process per host core."""
+import os
+import subprocess
+import sys
+import tempfile
+
 import numpy as np
 import pytest
 import torch
@@ -78,6 +84,54 @@ def test_one_view_against_oracle(full, gpu, oracle):
     want_score = float((H_o.astype(np.float64) * f["H_inv"].cpu().double().numpy()).sum())
     s = f["sc"].run(f["w2c"][5:6], H_inv=f["H_inv"])["scores"].item()
     assert abs(s - want_score) <= 1e-4 * abs(want_score)
+
+
+def _oracle_workers(mode, P, seed, W, H, n_poses, pose_seed, tmp, extra=()):
+    """the views [0, n_poses) cut over one tests/oracle_worker.py process per host core; returns the per-process outputs in order"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    n_proc = max(1, min(cores, 16, n_poses))
+    bounds = [round(k * n_poses / n_proc) for k in range(n_proc + 1)]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py")
+    procs, outs = [], []
+    for k in range(n_proc):
+        out = os.path.join(tmp, f"{mode}_{k}.npy")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, worker, mode, str(P), str(seed), str(W), str(H), str(n_poses), str(pose_seed),
+                                       str(bounds[k]), str(bounds[k + 1]), out, *extra]))
+    for pr in procs:
+        assert pr.wait(timeout=900) == 0
+    return [np.load(o) for o in outs]
+
+
+def test_all_64_scores_of_configs1_against_the_oracle(full, gpu, oracle):
+    """BASELINE.json configs[1] end to end as gaussian.py:1338-1375 runs it: H_train = sum of cur_H over the 16 keyframes, then
+    score_v = sum(cur_H_v / (H_train + 0.1)) for the 64 candidates -- the oracle's, from 80 full-size oracle views (one process
+    per host core), against the scorer's: 1e-4 on every score, exact visible / tile-instance counts."""
+    f = full
+    P, V, W, H = f["P"], f["V"], f["W"], f["H"]
+    with tempfile.TemporaryDirectory() as tmp:
+        parts = _oracle_workers("hessian", P, 2, W, H, 16, 102, tmp)
+        H_train = np.zeros((P, 4), np.float32)
+        for cur in np.concatenate(parts):                          # fp32 adds in keyframe order, gaussian.py:1343-1347
+            H_train += cur
+        H_inv_o = (np.float32(1.0) / (H_train + np.float32(0.1))).astype(np.float32)
+        hp = os.path.join(tmp, "H_inv.npy")
+        np.save(hp, H_inv_o)
+        rows = np.concatenate(_oracle_workers("scores", P, 2, W, H, V, 2, tmp, extra=(hp,)))
+    want, vis_o, nr_o = rows[:, 0], rows[:, 1].astype(np.int64), rows[:, 2].astype(np.int64)
+    # H_train of the scorer (16 keyframes, one launch) entry by entry against the oracle's
+    Ht = f["Ht"].cpu().numpy()
+    assert (np.abs(Ht - H_train) <= 1e-4 * np.abs(H_train) + 1e-7 * np.abs(H_train).max()).all()
+    got = f["sc"].run(f["w2c"], H_inv=f["H_inv"])                  # the product's own H_inv = 1 / (its H_train + 0.1)
+    s = got["scores"].cpu().numpy().astype(np.float64)
+    assert np.array_equal(got["vis_count"].cpu().numpy(), vis_o)
+    assert np.array_equal(got["num_rendered"].cpu().numpy(), nr_o)
+    err = np.abs(s - want) / np.abs(want)
+    assert err.max() < 1e-4, (float(err.max()), int(err.argmax()))
+    print(f"configs[1]: 64 scores vs oracle: max rel err {err.max():.2e}, median {np.median(err):.2e}")
 
 
 def test_config4_train_step_against_oracle(gpu, oracle):
