@@ -304,18 +304,23 @@ def valu_ceiling():
 
 
 def pmc_record(P, V, W, C):
-    """Hardware counters of ONE k_fisher_tile_v3 launch, collected by tools/pmc_collect.sh (rocprofv3 --pmc, separate
-    passes) and folded by tools/pmc_summary.py into profiles/pmc_k_fisher_tile_v3.json together with the commit and the
-    hash of the kernel sources they were taken from.  A record taken from other sources is reported as stale and not used."""
+    """Hardware counters of the k_fisher_tile_v3 dispatches of ONE step, collected by tools/pmc_collect.sh (rocprofv3 --pmc, separate
+    passes) and folded by tools/pmc_summary.py into profiles/pmc_k_fisher_tile_v3.json.  The record carries the sha256 of the kernel's
+    gfx950 machine code as it sat in the library the counters were taken on (tools/codeobj.py); it is used only when the library
+    loaded NOW holds the same code -- recomputed here, so there is no stamp to maintain by hand."""
     from fisher_rast import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj
     f = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v3.json")
     if not os.path.exists(f):
         return None, {"file": None, "fresh": False, "why": "no PMC record committed"}
     pm = json.load(open(f))
-    meta = {"file": "profiles/pmc_k_fisher_tile_v3.json", "commit": pm.get("commit"), "source_hash": pm.get("source_hash"),
-            "fresh": True, "source": "cached: rocprofv3 --pmc passes of tools/pmc_collect.sh, not measured in this run"}
-    if pm.get("source_hash") != _lib.source_hash():
-        meta.update(fresh=False, why=f"kernel sources changed since the counters were taken (now {_lib.source_hash()})")
+    now = codeobj.kernel_code_id(_lib.SO_PATH, "k_fisher_tile_v3I")
+    meta = {"file": "profiles/pmc_k_fisher_tile_v3.json", "commit": pm.get("commit"), "kernel_code_id": pm.get("kernel_code_id"),
+            "kernel_code_id_loaded": now, "fresh": True,
+            "source": "cached: rocprofv3 --pmc passes of tools/pmc_collect.sh, not measured in this run"}
+    if pm.get("kernel_code_id") is None or pm.get("kernel_code_id") != now:
+        meta.update(fresh=False, why="the loaded library's k_fisher_tile_v3 is not the code the counters were taken on")
     elif not (pm.get("gaussians") == P and pm.get("views") == V and pm.get("size") == W and pm.get("columns") == C):
         meta.update(fresh=False, why="counters were taken on another workload")
     return (pm if meta["fresh"] else None), meta
@@ -366,7 +371,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # FR_FORCE_COLLECTIVES=1 under `torch.distributed.run --nproc-per-node 1`: a process group of one rank, so that RCCL is loaded
+    # and the step's all-gather / the H_train all-reduce run on the device tensors (rehearsal of the transport on one GPU)
+    dist_on = world > 1 or (os.environ.get("FR_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -401,11 +409,12 @@ def main():
     vis_count = first["vis_count"].cpu().numpy().astype(np.int64)
 
     host_scores = torch.empty((V_total,), dtype=torch.float32).pin_memory()
+    gather = D.ScoreGather(V_total, dev) if dist_on else None         # the step's all-gather, buffers allocated once
 
     def step():
         r = scorer.launch(w2c, H_inv=H_inv)
-        if world > 1:
-            host_scores.copy_(D.gather_scores(r["scores"], V_total), non_blocking=True)
+        if dist_on:
+            host_scores.copy_(gather(r["scores"]), non_blocking=True)
         else:
             host_scores.copy_(r["scores"], non_blocking=True)
         return r
@@ -413,7 +422,7 @@ def main():
     for _ in range(a.warmup):
         step()
     lib = _lib.load()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     lib.fr_profile_enable(1)
@@ -422,7 +431,7 @@ def main():
     for _ in range(a.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     buf = (ctypes.c_float * max(a.steps * 16, 1))()
@@ -434,7 +443,7 @@ def main():
     kern_ms = float(np.mean([buf[i] for i in range(n_ev)])) if n_ev > 0 else float("nan")
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
     if rank == 0 and a.dump_scores:
@@ -453,21 +462,26 @@ def main():
         # whole-path algorithmic bytes per view, SURVEY.md 8(d)
         B_view = (12 * P + 44 * vis_count.mean() + 24 * num_rendered.mean() + 40 * num_rendered.mean() +
                   40 * num_rendered.mean() + 24 * W * H + 8 * W * H + 4 * C * P)
-        pm, pmc_meta = pmc_record(P, V // launches_per_step, W, C)
-        traffic = pm.get("hbm_bytes_per_launch") if pm else None
+        pm, pmc_meta = pmc_record(P, V, W, C)
+        if pm and pm.get("dispatches_per_step") != launches_per_step:
+            pm, pmc_meta = None, dict(pmc_meta, fresh=False, why="counters were taken with another number of view groups per step")
+        # per LAUNCH like `achieved`: the record sums the step's dispatches
+        traffic = pm["hbm_bytes_per_step"] / launches_per_step if pm and pm.get("hbm_bytes_per_step") else None
         ceil = valu_ceiling() if world == 1 else None
         valu = None
         if pm and pm.get("SQ_INSTS_VALU") and kern_ms == kern_ms:
-            rate = pm["SQ_INSTS_VALU"] / (kern_ms * 1e-3)
-            valu = {"bound": "valu", "insts_per_launch": pm["SQ_INSTS_VALU"], "achieved_wave_insts_per_s": rate,
-                    "lds_insts_per_launch": pm.get("SQ_INSTS_LDS"), "salu_insts_per_launch": pm.get("SQ_INSTS_SALU")}
+            step_ms = kern_ms * launches_per_step                    # the step's dispatches, summed
+            rate = pm["SQ_INSTS_VALU"] / (step_ms * 1e-3)
+            valu = {"bound": "valu", "insts_per_step": pm["SQ_INSTS_VALU"], "achieved_wave_insts_per_s": rate,
+                    "lds_insts_per_step": pm.get("SQ_INSTS_LDS"), "salu_insts_per_step": pm.get("SQ_INSTS_SALU")}
             if ceil and "independent_fma_wave_insts_per_s" in ceil:
                 valu["peak_wave_insts_per_s"] = ceil["independent_fma_wave_insts_per_s"]
                 valu["frac"] = rate / ceil["independent_fma_wave_insts_per_s"]
-            if pm.get("contributing_pairs_per_launch"):
+            if pm.get("contributing_pairs_per_step"):
                 # the pair-proportional work next to the GB/s (no atomics on the scoring path)
-                valu["pairs_per_s"] = pm["contributing_pairs_per_launch"] / (kern_ms * 1e-3)
-                valu["wave_insts_per_pair"] = pm["SQ_INSTS_VALU"] / pm["contributing_pairs_per_launch"]
+                valu["pairs_per_s"] = pm["contributing_pairs_per_step"] / (step_ms * 1e-3)
+                valu["wave_insts_per_pair"] = pm["SQ_INSTS_VALU"] / pm["contributing_pairs_per_step"]
+                valu["walk_iterations_per_step"] = pm.get("walk_iterations_per_step")
         out = {
             "metric": "candidate-views/sec", "value": views_per_s, "unit": "candidate-views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -539,8 +553,11 @@ def main():
                 out["config4"] = config4_train_step(dev)
         else:
             out["cpu_baseline"] = None
+        if dist_on:
+            out["collectives"] = {"backend": dist.get_backend(), "world_size": world,
+                                  "per_step": "all_gather_into_tensor of the per-view scores (fisher_rast.distributed.ScoreGather)"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -3143,11 +3143,15 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 }
 
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
-                                                              const int* __restrict__ status, float* __restrict__ out_scores,
+                                                              const int* __restrict__ status, int n_groups, float* __restrict__ out_scores,
                                                               int* __restrict__ status_out)
 {
-	if (blockIdx.x == 0 && threadIdx.x < 4) status_out[threadIdx.x] = status[threadIdx.x];   // the caller's copy of {total, overflow, max, 0}
-	if (status[1]) return;
+	// status: one {total, overflow, max tile count, 0} per view group of the call; the caller's copy is {sum, any, max, 0}, and an
+	// overflow of ANY group leaves every score unwritten (the caller grows the buffer and repeats the call)
+	int tot = 0, ovf = 0, mx = 0;
+	for (int g = 0; g < n_groups; g++) { tot += status[4 * g]; ovf |= status[4 * g + 1]; mx = status[4 * g + 2] > mx ? status[4 * g + 2] : mx; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) { status_out[0] = tot; status_out[1] = ovf; status_out[2] = mx; status_out[3] = 0; }
+	if (ovf || !out_scores) return;
 	__shared__ double s_part[FR_THREADS];
 	const int v = blockIdx.x, tid = threadIdx.x;
 	double s = 0.0;
@@ -3929,6 +3933,20 @@ static inline int fr_pick_VC(long long T)
 	if (vc > 4) vc = 4;                                       // 4 views per workgroup: 2.16 ms per step against 2.20 for 8 and 2.19 for 2
 	return (int)(vc < 1 ? 1 : (vc > 8 ? 8 : vc));
 }
+// View groups of a records-mode fr_fisher_views call (see there).  FR_GROUPS=<n> (A/B runs): n groups; default ONE launch for all
+// views.  Measured on MI355X (500k Gaussians x 64 views, profiles/r03_b_groups_timeline.txt): with 2 groups the second group's
+// projection kernel keeps its speed under the first group's tile kernel (334 vs 341 us), but the tile kernel takes 973 us
+// instead of 540 and the scan / scatter / sort tiers beside it 2-8x their time -- 2.32 ms per step against 2.10 (4 groups: 2.56;
+// the tile stream at the lowest or the highest priority: the same).  Both halves want the same wave slots and the same L2.
+static inline int fr_pick_groups(int V)
+{
+	static int forced = -1;
+	if (forced < 0) { const char* e = getenv("FR_GROUPS"); forced = e ? atoi(e) : 0; }
+	int n = forced > 0 ? forced : 1;
+	if (n > 4) n = 4;                                         // FR_MAX_GROUPS
+	while (n > 1 && V < 16 * n) n--;                          // at least 16 views per group
+	return n;
+}
 static inline long long fr_preprocess_blocks(long long P, long long V)
 {
 	// the larger of the two decompositions fr_bin_pipeline can pick (blk_base is sized with it)
@@ -4072,21 +4090,27 @@ struct FrZeroer {
 	}
 };
 
-// Two side streams per host thread and device for the fork/joins inside fr_bin_pipeline (created on first use, or by
-// fr_init; they live with the thread): [0] the 1024-thread sort tier, [1] the scorer's per-(view, Gaussian) records.
+// Three side streams per host thread and device (created on first use, or by fr_init; they live with the thread):
+// [0] the 1024-thread sort tier and [1] the scorer's per-(view, Gaussian) records of the single-view front end (fork / joins inside
+// fr_bin_pipeline); [2] the tile kernels of fr_fisher_views when a call is cut into view groups (below).
 struct FrSideStream {
 	hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; int device = -1;
 };
 static FrSideStream& fr_side_stream(int which = 0)
 {
-	static thread_local FrSideStream sides[2];
+	static thread_local FrSideStream sides[3];
 	FrSideStream& ss = sides[which];
 	int dev = -1;
 	(void)hipGetDevice(&dev);
 	if (ss.device != dev)
 	{
 		if (ss.ok) { (void)hipEventDestroy(ss.fork); (void)hipEventDestroy(ss.join); (void)hipStreamDestroy(ss.stream); }
-		ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess
+		// FR_TILE_PRIO=<-1|0|1> (A/B runs): priority of the tile stream [2] relative to the default: 1 = lowest, -1 = highest
+		static const int tile_prio = [] { const char* e = getenv("FR_TILE_PRIO"); return e ? atoi(e) : 0; }();
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least priority (largest number), hi = greatest
+		const int prio = (which == 2 && tile_prio > 0) ? lo : (which == 2 && tile_prio < 0) ? hi : 0;
+		ss.ok = hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio) == hipSuccess
 		     && hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess
 		     && hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
 		ss.device = dev;
@@ -4118,7 +4142,7 @@ struct FrJoinGuard {
 
 // Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
 // k_preprocess_views; with the single-view front end, k_fisher_records after k_scatter_keys, beside the sorts, on the second side stream).
-struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; };     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
+struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; bool skip_pack = false; };   // skip_pack: a view group after the first (the packed static records are per call)     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
 template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed, float* __restrict__ cov_trace);
 template <int C, bool LIST, bool FORM_A> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
 
@@ -4147,7 +4171,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	const int per_block = FR_THREADS * p.G;
 	dim3 gridP((P + per_block - 1) / per_block, p.V);
 	const size_t hist_lds = p.T <= FR_MAX_LDS_TILES ? (size_t)p.T * 4 : 16;
-	if (plan)
+	if (plan && !plan->skip_pack)
 	{
 		const float* shared_hinv = plan->ra.hinv_stride ? nullptr : plan->ra.H_inv;
 		dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
@@ -4513,6 +4537,7 @@ static int fr_debug_mode()
 	return mode;
 }
 
+#define FR_MAX_GROUPS 4              // view groups of one fr_fisher_views call (fr_pick_groups)
 struct FrFisherLayout {
 	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 	size_t PV;                   // slots per view of the compact records: projection workgroups * 256 G (>= P)
@@ -4536,7 +4561,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.slot_idx = o; o = fr_align(o + VPV * 4);
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.cov_trace = o; o = fr_align(o + (size_t)P * 4);
-	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64);
+	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64 * FR_MAX_GROUPS);      // one {count, pad[15], list} per view group
 	L.blk_base = o; o = fr_align(o + (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4);
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
@@ -4562,7 +4587,7 @@ extern "C" int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32
 
 extern "C" int fr_init(void)
 {
-	if (!fr_side_stream(0).ok || !fr_side_stream(1).ok) return fr_fail(FR_ELAUNCH, "fr_init: could not create the side streams");
+	if (!fr_side_stream(0).ok || !fr_side_stream(1).ok || !fr_side_stream(2).ok) return fr_fail(FR_ELAUNCH, "fr_init: could not create the side streams");
 	return FR_OK;
 }
 
@@ -4721,21 +4746,82 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	// the early frustum test needs a positive semi-definite cov3D: the one k_cov3d builds, not a caller's precomputed one;
 	// FR_DEBUG_MODE=15 switches it off (A/B runs)
 	plan.ra.cov_trace = (g->cov3D_precomp || f.debug_mode == 15) ? nullptr : (const float*)(ws + L.cov_trace);
-	if ((rc = fr_bin_pipeline(p, g, s, (v3 || v3h) ? &plan : nullptr))) return rc;
 
-	if (v3) fr_launch_fisher_v3(p, f, plan.ra.recq, s);
-	else if (v3h) fr_launch_fisher_v3h(p, f, plan.ra.recq, s);
-	else if (fc->columns == 4) fr_launch_fisher<4>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
-	else fr_launch_fisher<11>(p, f, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), s);
-
-	if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
-	if (fc->out_scores)
+	// ---- view groups (off by default: fr_pick_groups has the measurement).  The front end (projection, records, scan, scatter,
+	// sorts: ~1.1 ms at 500k Gaussians x 64 views) waits on memory for half its wave cycles, the tile kernel (~1.0 ms) is bound by
+	// VALU issue; to let them overlap, a records-mode call can be cut into groups of whole multiples of 8 views (the XCD map of the
+	// tile kernels): the groups' front ends run one after the other on the caller's stream, every group's tile kernel on a side
+	// stream as soon as ITS front end is done -- underneath the next group's front end.  A view's tiles are computed by the same
+	// code on the same data whatever the grouping, so the scores are bit-identical to the single-group launch
+	// (tests/test_gpu_bench_multirank.py::test_view_groups_give_the_same_scores).
+	const bool multi = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;
+	const int n_groups = (v3 && multi) ? fr_pick_groups(V) : 1;      // (score-only: an out_H launch must accumulate all or nothing on overflow)
+	FrSideStream& tside = fr_side_stream(2);
+	const bool use_side = n_groups > 1 && tside.ok;
+	hipStream_t ts = use_side ? tside.stream : s;                  // the tile kernels' stream
+	static thread_local hipEvent_t front_done[FR_MAX_GROUPS] = { nullptr, nullptr, nullptr, nullptr };
+	const size_t nblk_v = (size_t)((P + FR_THREADS * fr_pick_G_views(P) - 1) / (FR_THREADS * fr_pick_G_views(P)));
+	const size_t cap_v = (size_t)(FR_THREADS * fr_pick_G_views(P));
+	const size_t rec_view = compact ? L.PV : (size_t)P;            // records per view in the splat / record regions
+	struct TileJoin {                                              // the caller's stream waits for the tile stream on every way out
+		hipStream_t s; FrSideStream* side; bool on;
+		~TileJoin() { if (on) { (void)hipEventRecord(side->join, side->stream); (void)hipStreamWaitEvent(s, side->join, 0); } }
+	} tile_join{ s, &tside, false };
+	for (int gi = 0; gi < n_groups; gi++)
 	{
-		hipLaunchKernelGGL(k_reduce_scores, dim3(V), dim3(FR_THREADS), 0, s, f.tile_scores, p.T, p.status, fc->out_scores, status);
-		if ((rc = fr_check_launch("k_reduce_scores"))) return rc;
+		// contiguous view slices, every one but the last a multiple of 8 views
+		const int per = n_groups > 1 ? ((V / n_groups + 7) / 8) * 8 : V;
+		const int v0 = gi * per, Vg = (gi == n_groups - 1) ? V - v0 : per;
+		if (Vg <= 0) break;
+		FrParams pg = p;
+		pg.V = Vg;
+		pg.w2c = p.w2c + 16 * (size_t)v0;
+		pg.radii = p.radii ? (int*)((char*)p.radii + (size_t)v0 * nblk_v * cap_v * sizeof(FrVisEntry)) : nullptr;
+		pg.vis_list = p.vis_list + (size_t)v0 * nblk_v * cap_v;
+		pg.vis_n = p.vis_n + (size_t)v0 * nblk_v;
+		pg.splat = p.splat + (size_t)v0 * rec_view;
+		pg.tile_cnt = p.tile_cnt + (size_t)v0 * p.T; pg.tile_off = p.tile_off + (size_t)v0 * p.T; pg.tile_fill = p.tile_fill + (size_t)v0 * p.T;
+		pg.status = p.status + 4 * gi;
+		pg.big_list = p.big_list + (size_t)v0 * p.T + 16 * gi;
+		pg.blk_base = p.blk_base + (size_t)v0 * (size_t)fr_preprocess_blocks(P, V) * (size_t)p.T;
+		const long long k0 = (long long)((__int128)max_rendered * v0 / V), k1 = (long long)((__int128)max_rendered * (v0 + Vg) / V);
+		pg.keys = p.keys + k0; pg.key_capacity = k1 - k0;
+		pg.vis_count = p.vis_count ? p.vis_count + v0 : nullptr;
+		pg.num_rendered = p.num_rendered ? p.num_rendered + v0 : nullptr;
+		FrScorerPlan pl = plan;
+		pl.skip_pack = gi > 0;
+		if (pl.ra.hinv_stride) pl.ra.H_inv = plan.ra.H_inv + (size_t)v0 * plan.ra.hinv_stride;
+		pl.ra.recq = plan.ra.recq + (size_t)v0 * rec_view * 4;
+		if (pl.ra.comp) pl.ra.comp = plan.ra.comp + (size_t)v0 * L.PV * 6;
+		if (pl.ra.slot_idx) pl.ra.slot_idx = plan.ra.slot_idx + (size_t)v0 * L.PV;
+		FrFisherArgs fg = f;
+		fg.recA = f.recA + (size_t)v0 * f.ab_view; fg.recQ = f.recQ + (size_t)v0 * f.q_view;
+		if (f.slot_idx) fg.slot_idx = f.slot_idx + (size_t)v0 * f.slot_view;
+		fg.tile_scores = f.tile_scores + (size_t)v0 * p.T;
+		if (f.H_inv && f.hinv_stride) fg.H_inv = f.H_inv + (size_t)v0 * f.hinv_stride;
+		if (f.out_H && f.outH_stride) fg.out_H = f.out_H + (size_t)v0 * f.outH_stride;
+		if (f.dL_img && f.dL_stride) fg.dL_img = f.dL_img + (size_t)v0 * f.dL_stride;
+
+		if ((rc = fr_bin_pipeline(pg, g, s, (v3 || v3h) ? &pl : nullptr))) return rc;
+		if (use_side)
+		{
+			if (!front_done[gi] && hipEventCreateWithFlags(&front_done[gi], hipEventDisableTiming) != hipSuccess)
+				return fr_fail(FR_ELAUNCH, "fr_fisher_views: hipEventCreate failed");
+			if (hipEventRecord(front_done[gi], s) != hipSuccess || hipStreamWaitEvent(ts, front_done[gi], 0) != hipSuccess)
+				return fr_fail(FR_ELAUNCH, "fr_fisher_views: fork to the tile stream failed");
+			tile_join.on = true;
+		}
+		if (v3) fr_launch_fisher_v3(pg, fg, pl.ra.recq, ts);
+		else if (v3h) fr_launch_fisher_v3h(pg, fg, pl.ra.recq, ts);
+		else if (fc->columns == 4) fr_launch_fisher<4>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
+		else fr_launch_fisher<11>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
+		if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
 	}
-	else (void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
-	return FR_OK;
+	// scores in a fixed order + the caller's status word {sum of tile instances, any overflow, max, 0}
+	hipLaunchKernelGGL(k_reduce_scores, dim3(fc->out_scores ? V : 1), dim3(FR_THREADS), 0, ts, f.tile_scores, p.T, p.status, n_groups,
+	                   fc->out_scores, status);
+	if ((rc = fr_check_launch("k_reduce_scores"))) return rc;
+	return FR_OK;                                                    // (tile_join: the caller's stream now waits for the tile stream)
 }
 
 // =========================================================================================================

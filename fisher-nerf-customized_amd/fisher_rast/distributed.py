@@ -8,10 +8,20 @@ The reference has no distributed code; this is new work sp
   * H_train = keyframes sharded across ranks + ONE all-reduce(SUM) of the [P, C] fp32 accumulator.
 No collective touches the per-pixel / per-splat data path.
 """
+import os
 from typing import Callable, Optional
 
 import torch
 import torch.distributed as dist
+
+# FR_FORCE_COLLECTIVES=1: issue the collectives in a process group of ONE rank too (they are no-ops for the data, but the
+# transport -- RCCL on a GPU box -- is loaded, initialised and run on the device tensors): the one-GPU rehearsal of the
+# multi-GPU path (tests/test_gpu_bench_multirank.py)
+FORCE_COLLECTIVES = os.environ.get("FR_FORCE_COLLECTIVES") == "1"
+
+
+def _collective(world: int) -> bool:
+    return world > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 def shard_bounds(n: int, rank: int, world: int):
@@ -32,23 +42,60 @@ def _host_collectives(t: torch.Tensor, group=None) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+class ScoreGather:
+    """The per-step all-gather of the per-view scores with every buffer allocated ONCE (a planning loop calls it every step):
+    contiguous shards of possibly unequal length -> [n_total] on every rank.  V % world == 0: the local scores go straight into
+    `all_gather_into_tensor` and its output IS the result (no padding, no copy); otherwise the shards are padded to the longest
+    one and the result is one `index_select` of the padded gather.  The returned tensor is overwritten by the next call."""
+
+    def __init__(self, n_total: int, device, dtype=torch.float32, group=None):
+        self.group, self.n_total = group, int(n_total)
+        self.rank, self.world = _world(group)
+        self.active = _collective(self.world)
+        self.host = self.active and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+        dev = torch.device("cpu") if self.host else torch.device(device)
+        self.device = torch.device(device)
+        self.lo, self.hi = shard_bounds(self.n_total, self.rank, self.world)
+        self.even = self.n_total % max(self.world, 1) == 0
+        per = (self.n_total + self.world - 1) // max(self.world, 1)
+        self.out = torch.empty((self.world * per,), dtype=dtype, device=dev)
+        if not self.even:
+            self.pad = torch.zeros((per,), dtype=dtype, device=dev)
+            idx = []
+            for r in range(self.world):
+                lo, hi = shard_bounds(self.n_total, r, self.world)
+                idx += list(range(r * per, r * per + (hi - lo)))
+            self.index = torch.tensor(idx, dtype=torch.int64, device=dev)
+            self.result = torch.empty((self.n_total,), dtype=dtype, device=dev)
+        self.dev_result = torch.empty((self.n_total,), dtype=dtype, device=self.device) if self.host else None
+
+    def __call__(self, local_scores: torch.Tensor) -> torch.Tensor:
+        if not self.active:
+            return local_scores
+        assert local_scores.numel() == self.hi - self.lo
+        src = local_scores
+        if self.host:                         # gloo rehearsal: collectives on host tensors
+            src = local_scores.cpu()
+        if self.even:
+            dist.all_gather_into_tensor(self.out, src.contiguous(), group=self.group)
+            res = self.out
+        else:
+            self.pad[: src.numel()].copy_(src)
+            dist.all_gather_into_tensor(self.out, self.pad, group=self.group)
+            torch.index_select(self.out, 0, self.index, out=self.result)
+            res = self.result
+        if self.host:
+            self.dev_result.copy_(res)
+            return self.dev_result
+        return res
+
+
 def gather_scores(local_scores: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """All-gather of per-view scores from contiguous shards of possibly unequal length -> [n_total] on every rank."""
+    """One-off form of ScoreGather (allocates its buffers per call; a loop should hold a ScoreGather)."""
     rank, world = _world(group)
-    if world == 1:
+    if not _collective(world):
         return local_scores
-    if _host_collectives(local_scores, group):
-        return gather_scores(local_scores.cpu(), n_total, group).to(local_scores.device)
-    per = (n_total + world - 1) // world
-    buf = torch.zeros((per,), dtype=local_scores.dtype, device=local_scores.device)
-    buf[: local_scores.numel()] = local_scores
-    out = torch.empty((world * per,), dtype=local_scores.dtype, device=local_scores.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
-    parts = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, r, world)
-        parts.append(out[r * per: r * per + (hi - lo)])
-    return torch.cat(parts)
+    return ScoreGather(n_total, local_scores.device, local_scores.dtype, group)(local_scores).clone()
 
 
 def sharded_scores(score_fn: Callable[[torch.Tensor], torch.Tensor], w2c_all: torch.Tensor, group=None) -> torch.Tensor:
@@ -72,7 +119,7 @@ def sharded_h_train(accumulate_fn: Callable[[torch.Tensor, torch.Tensor], None],
     lo, hi = shard_bounds(K, rank, world)
     if hi > lo:
         accumulate_fn(kf_w2c[lo:hi], H_train)
-    if world > 1:
+    if _collective(world):
         _all_reduce(H_train, dist.ReduceOp.SUM, group)
     return H_train
 
@@ -98,7 +145,7 @@ def sharded_point_score_max(scorer, w2c_all: torch.Tensor, H_inv: torch.Tensor, 
         cur = torch.zeros((int(w.shape[0]), scorer.P, scorer.columns), dtype=torch.float32, device=w2c_all.device)
         scorer.run(w, out_H=cur, out_H_per_view=True)
         best = torch.maximum(best, (cur * H_inv.unsqueeze(0)).sum(dim=2).max(dim=0).values)
-    if world > 1:
+    if _collective(world):
         _all_reduce(best, dist.ReduceOp.MAX, group)
     return best
 

@@ -268,8 +268,8 @@ class FisherScorer:
         self.campos = _prep(raster_settings.campos, d)
         self._ws = {}
         self._side_streams = []
-        # measured on MI355X (500k Gaussians, 64 views): 2 groups on 2 streams 7.6 ms per step against 6.5 ms for one launch --
-        # the half-size launches lose more than the overlap gains, so one group is the default
+        # measured on MI355X (500k Gaussians, 64 views; round 3 kernels): 2 groups on 2 streams 2.47 ms per step against 2.08 ms for
+        # one launch, 4 groups 2.76 ms (the staggered form inside fr_fisher_views, FR_GROUPS: 2.32 / 2.56) -- one group is the default
         self.n_streams = max(1, int(os.environ.get("FR_STREAMS", "1")))
         self.per_view_capacity = max(int(0.75 * self.P), 1 << 16)
         self.cfg = _raster_cfg(self.P, self.H, self.W, raster_settings.tanfovx, raster_settings.tanfovy,
@@ -387,7 +387,6 @@ class FisherScorer:
             oh = out_H
             if out_H is not None and out_H_per_view:
                 oh = out_H.view(V, -1)[v0:v1]
-            snapshot = oh.clone() if oh is not None else None
             while True:
                 dl = dL_image
                 if dL_image is not None and dL_image.dim() == 4 and dL_image.shape[0] == V:
@@ -396,9 +395,8 @@ class FisherScorer:
                 st = r["status"].cpu()
                 if int(st[1]) == 0:
                     break
-                # tile-instance buffer too small: nothing was scored or accumulated; grow and redo this chunk
-                if snapshot is not None:
-                    oh.copy_(snapshot)
+                # tile-instance buffer too small: NOTHING was scored or accumulated (every kernel behind the scan returns on the
+                # overflow flag, include/fisher_rast.h), so out_H is as it was: grow and redo this chunk
                 self.per_view_capacity = int(int(st[0]) * 1.25 / (v1 - v0)) + 4096
                 chunk = min(chunk, self.max_views_per_launch())
                 if v1 - v0 > chunk:
@@ -407,7 +405,6 @@ class FisherScorer:
                         hi = H_inv.reshape(V, -1)[v0:v1]
                     if out_H is not None and out_H_per_view:
                         oh = out_H.view(V, -1)[v0:v1]
-                        snapshot = oh.clone()
             outs.append(r)
             v0 = v1
         res = dict(vis_count=torch.cat([o["vis_count"] for o in outs]),

@@ -25,7 +25,55 @@ from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 from fisher_rast.ops import FisherScorer
 from models.SLAM.utils.common_utils import checkpoint_time_idx, load_params_ckpt, save_params, save_params_ckpt
 from models.SLAM.utils.recon_helpers import setup_camera
-from models.SLAM.utils.slam_helpers import transformed_params2rendervar, transformed_params2depthplussilhouette
+from models.SLAM.utils.slam_helpers import (transformed_params2rendervar, transformed_params2depthplussilhouette,
+                                            render_rgb_depth_sil)
+from models.SLAM.utils.slam_external import update_seen_and_radius
+
+
+def make_get_loss(transform_to_frame, calc_loss):
+    """Drop-in for the module-level `get_loss` of the reference (models/SLAM/gaussian.py:184-297): same signature, same return
+    `(loss, variables, weighted_losses)`.  What changes: the two rasteriser calls of 205-211 (RGB, then depth / silhouette /
+    depth^2 on the same Gaussians) are ONE projection / binning / sort with two compositing passes and one fused backward
+    (`render_rgb_depth_sil` -> fr_forward_pair / fr_backward_pair), and the `seen` / `max_2D_radius` update of 289-291 is one
+    kernel pass (fr_densify_stats).  The masks and the loss terms are the reference's own `calc_loss` and the pose / point
+    transform its own `transform_to_frame` (models/SLAM/utils/slam_helpers.py:23-44, 282-317), handed in by the caller --
+    `FisherOps.install` takes them from the reference module it patches.  The matplotlib dump of 240-284 is not reproduced
+    (visualize_tracking_loss is accepted and ignored)."""
+    @torch.enable_grad()
+    def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss,
+                 sil_thres, use_l1, ignore_outlier_depth_loss, tracking=False,
+                 mapping=False, do_ba=False, plot_dir=None, visualize_tracking_loss=False, tracking_iteration=None):
+        if tracking:
+            transformed_pts = transform_to_frame(params, iter_time_idx, gaussians_grad=False, camera_grad=True)
+        elif mapping:
+            transformed_pts = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=False)
+        else:
+            raise ValueError("get_loss: one of tracking / mapping must be set")     # (the reference fails with a NameError here)
+        im, radius, depth_sil, rendervar = render_rgb_depth_sil(params, curr_data['cam'], curr_data['w2c'], transformed_pts)
+        variables['means2D'] = rendervar['means2D']      # gradient only accumulates from the colour render (gaussian.py:207)
+        depth = depth_sil[0, :, :].unsqueeze(0)
+        silhouette = depth_sil[1, :, :]
+        presence_sil_mask = (silhouette > sil_thres)
+        depth_sq = depth_sil[2, :, :].unsqueeze(0)
+        uncertainty = (depth_sq - depth ** 2).detach()
+        nan_mask = (~torch.isnan(depth)) & (~torch.isnan(uncertainty))
+        if ignore_outlier_depth_loss:
+            depth_error = torch.abs(curr_data['depth'] - depth) * (curr_data['depth'] > 0)
+            mask = (depth_error < 10 * depth_error.median())
+            mask = mask & (curr_data['depth'] > 0)
+        else:
+            mask = (curr_data['depth'] > 0)
+        mask = mask & nan_mask
+        if tracking and use_sil_for_loss:
+            mask = mask & presence_sil_mask
+        color_mask = torch.tile(mask, (3, 1, 1)).detach()
+        losses = calc_loss(curr_data, im, depth, mask, color_mask, use_l1, use_sil_for_loss, ignore_outlier_depth_loss, tracking)
+        weighted_losses = {k: v * loss_weights[k] for k, v in losses.items()}
+        loss = sum(weighted_losses.values())
+        update_seen_and_radius(variables, radius)        # variables['seen'], variables['max_2D_radius'] (gaussian.py:289-291)
+        weighted_losses['loss'] = loss
+        return loss, variables, weighted_losses
+    return get_loss
 
 
 class FisherOps:
@@ -112,7 +160,7 @@ class FisherOps:
         if len(self.keyframe_list) == 0:
             return None
         scorer = self._scorer(random_gaussians if self.FISHER_COLUMNS == 11 else None)   # shared with pose_eval's scoring launch
-        w2cs = torch.stack([self._as_w2c(kf['est_w2c']) for kf in self.keyframe_list])
+        w2cs = self._stack_poses([kf['est_w2c'] for kf in self.keyframe_list])
         H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
         scorer.run(w2cs, out_H=H_train)
         return H_train
@@ -121,15 +169,37 @@ class FisherOps:
         """ API Setting """
         return 1
 
+    def _stack_poses(self, poses):
+        """[V,4,4] fp32 on the device from a tensor, an array, or a list of either: one stack and one transfer, not V of them"""
+        dev = self._device()
+        if isinstance(poses, torch.Tensor):
+            return poses.reshape(-1, 4, 4).to(dev).float()
+        if isinstance(poses, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(poses.reshape(-1, 4, 4))).to(dev).float()
+        if len(poses) and all(isinstance(p, torch.Tensor) and p.device == dev for p in poses):
+            return torch.stack(list(poses)).float()
+        return torch.from_numpy(np.stack([np.asarray(p.detach().cpu() if isinstance(p, torch.Tensor) else p) for p in poses])).to(dev).float()
+
     def pose_eval(self, poses, random_gaussian_params=None, criterion=None):
-        """Scores of candidate poses (gaussian.py:1354-1375): returns (scores cpu fp32 [V], stack(c2w) [V,4,4])."""
+        """Scores of candidate poses (gaussian.py:1354-1375): returns (scores cpu fp32 [V], stack(c2w) [V,4,4]).
+        H_train over the keyframes and the candidate scores are two launches on one stream with ONE host synchronisation:
+        the two 16-byte status words travel to the host together with the scores."""
         extra = random_gaussian_params if self.FISHER_COLUMNS == 11 else None
-        H_train = self.compute_H_train(extra)
-        H_train_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
-        c2ws = [self._as_w2c(c2w) for c2w in poses]
-        c2w = torch.stack(c2ws)
+        c2w = self._stack_poses(poses)
         w2c = torch.linalg.inv(c2w)
         scorer = self._scorer(extra)
+        V, K = int(c2w.shape[0]), len(self.keyframe_list)
+        if 0 < K and max(V, K) <= scorer.max_views_per_launch():
+            kf = self._stack_poses([kf['est_w2c'] for kf in self.keyframe_list])
+            H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
+            r1 = scorer.launch(kf, out_H=H_train)
+            r2 = scorer.launch(w2c, H_inv=torch.reciprocal(H_train + self.H_TRAIN_REG))
+            host = torch.cat([r1["status"], r2["status"], r2["scores"].view(torch.int32)]).cpu()      # the one sync
+            if int(host[1]) == 0 and int(host[5]) == 0:
+                return host[8:].view(torch.float32).clone(), c2w
+            # the tile-instance buffer was too small (nothing was accumulated or scored): the growing path below repeats both
+        H_train = self.compute_H_train(extra)
+        H_train_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
         res = scorer.run(w2c, H_inv=H_train_inv)
         scores = res["scores"].cpu()
         return scores, c2w
@@ -143,8 +213,15 @@ class FisherOps:
     @classmethod
     def install(cls, target_cls):
         """Graft the accelerated methods onto the reference's class."""
-        for name in ("_device", "_as_w2c", "_scorer", "_scorer_key", "_PARAM_KEYS", "compute_Hessian", "compute_H_train", "pose_eval", "path_scores"):
+        for name in ("_device", "_as_w2c", "_stack_poses", "_scorer", "_scorer_key", "_PARAM_KEYS", "compute_Hessian", "compute_H_train",
+                     "pose_eval", "path_scores"):
             setattr(target_cls, name, getattr(cls, name))
+        # the module-level get_loss of the reference (gaussian.py:184-297), rebuilt around the reference module's own
+        # transform_to_frame / calc_loss: one fused render pair instead of two rasteriser calls
+        import sys
+        mod = sys.modules.get(target_cls.__module__)
+        if mod is not None and all(hasattr(mod, n) for n in ("get_loss", "transform_to_frame", "calc_loss")):
+            mod.get_loss = make_get_loss(mod.transform_to_frame, mod.calc_loss)
         if not hasattr(target_cls, "FISHER_COLUMNS"):
             target_cls.FISHER_COLUMNS = cls.FISHER_COLUMNS
         target_cls.H_TRAIN_REG = cls.H_TRAIN_REG

@@ -44,3 +44,29 @@ def test_two_rank_bench_equals_one_rank(gpu, tmp_path):
         assert j["metric"] == one["metric"] == "candidate-views/sec" and j["value"] > 0 and j["cpu_baseline"] is None
         assert j["roofline"]["kernel"] == "k_fisher_tile_v3" and j["roofline"]["kernel_ms"] > 0
     assert one["n_gpus"] == 1 and one["build"]["build_id"].startswith("FRSRC:")
+
+
+def test_one_rank_process_group_runs_the_collectives_through_rccl(gpu, tmp_path):
+    """No multi-GPU node here, but the transport can still be exercised: bench.py under torch.distributed.run with ONE rank and
+    the nccl backend (= RCCL), FR_FORCE_COLLECTIVES=1: the process group is created, the H_train all-reduce and the per-step
+    all_gather_into_tensor run on device tensors, and the scores equal the plain one-process run bit for bit."""
+    port = 29950 + os.getpid() % 40
+    plain, s0 = _run([sys.executable, "bench.py", "--gpus", "1", "--views", "16"] + COMMON, {}, str(tmp_path / "plain.npy"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "1", "--views", "16"] + COMMON
+    coll, s1 = _run(cmd, {"FR_FORCE_COLLECTIVES": "1", "FR_BENCH_BACKEND": "nccl"}, str(tmp_path / "rccl.npy"))
+    assert coll["collectives"]["backend"] == "nccl" and coll["collectives"]["world_size"] == 1
+    assert "collectives" not in plain
+    assert np.array_equal(s0, s1)
+
+
+def test_view_groups_give_the_same_scores(gpu, tmp_path):
+    """fr_fisher_views cut into view groups whose tile kernels run on a side stream under the next group's front end
+    (FR_GROUPS, off by default -- it measured slower): the scores must be bit-identical to the single launch."""
+    args = [sys.executable, "bench.py", "--gpus", "1", "--views", "64", "--steps", "2", "--warmup", "1", "--cpu-views", "0",
+            "--gaussians", "60000", "--size", "128", "--seed", "3", "--synthetic-hinv"]
+    one, s1 = _run(args, {"FR_GROUPS": "1"}, str(tmp_path / "g1.npy"))
+    two, s2 = _run(args, {"FR_GROUPS": "2"}, str(tmp_path / "g2.npy"))
+    four, s4 = _run(args, {"FR_GROUPS": "4"}, str(tmp_path / "g4.npy"))
+    assert one["roofline"]["launches_per_step"] == 1 and two["roofline"]["launches_per_step"] == 2 and four["roofline"]["launches_per_step"] == 4
+    assert s1.shape == (64,) and np.array_equal(s1, s2) and np.array_equal(s1, s4)

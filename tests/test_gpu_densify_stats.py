@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from gpu_util import assert_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -91,3 +93,65 @@ def test_mapping_iteration_with_the_drop_in_rasteriser(gpu, oracle):
     to_clone, to_split = se.densify_masks(params, variables, float(np.median(acc_o[seen_o])))
     c_o, s_o = ods.densify_masks(acc_o, den_o, params['log_scales'].detach().cpu().numpy(), float(np.median(acc_o[seen_o])))
     assert np.array_equal(to_clone.cpu().numpy(), c_o) and np.array_equal(to_split.cpu().numpy(), s_o) and c_o.sum() > 10
+
+
+def test_drop_in_get_loss_against_the_two_render_route(gpu):
+    """`make_get_loss` (the graft for the reference's module-level get_loss, gaussian.py:184-297) against the reference's own
+    structure -- two GaussianRasterizer calls, torch ops for `seen` / `max_2D_radius` -- on the same parameters, with the test's
+    stand-ins for the reference's transform_to_frame / calc_loss (mapping mode: L1 depth + 0.8 L1 + 0.2 (1 - ssim) colour,
+    the ssim term left out: it is the reference's own torch code either way)."""
+    import torch.nn.functional as F
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from fisher_rast import synthetic
+    from models.SLAM.gaussian import make_get_loss
+    from models.SLAM.utils.recon_helpers import setup_camera
+    from models.SLAM.utils.slam_helpers import transformed_params2rendervar, transformed_params2depthplussilhouette
+    P, W, H = 5000, 96, 80
+    base = synthetic.room_shell(P, seed=12)
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(1, seed=13))[0].to(gpu)
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    g = torch.Generator().manual_seed(3)
+    curr_data = dict(cam=cam, w2c=torch.eye(4, device=gpu), im=torch.rand((3, H, W), generator=g).to(gpu),
+                     depth=(torch.rand((1, H, W), generator=g) * 4 + 0.5).to(gpu))
+    curr_data['depth'][0, :4, :] = 0.0                      # invalid depth rows (mask)
+
+    def transform_to_frame(params, time_idx, gaussians_grad, camera_grad):    # stand-in: the pose is w2c, Gaussians get the gradient
+        pts = params['means3D'] if gaussians_grad else params['means3D'].detach()
+        return (w2c @ torch.cat((pts, torch.ones_like(pts[:, :1])), 1).T).T[:, :3]
+
+    def calc_loss(curr_data, im, depth, mask, color_mask, use_l1, use_sil_for_loss, ignore_outlier_depth_loss, tracking):
+        return dict(depth=torch.abs(curr_data['depth'] - depth)[mask.detach()].mean(), im=0.8 * torch.abs(im - curr_data['im']).mean())
+
+    weights = dict(im=0.5, depth=1.0)
+
+    def fresh():
+        params = {k: v.clone().to(gpu).requires_grad_(True) for k, v in base.items()}
+        variables = dict(max_2D_radius=torch.full((P,), 3.0, device=gpu), means2D_gradient_accum=torch.zeros(P, device=gpu), denom=torch.zeros(P, device=gpu))
+        return params, variables
+
+    # the graft
+    params, variables = fresh()
+    loss, variables, wl = make_get_loss(transform_to_frame, calc_loss)(params, curr_data, variables, 0, weights, True, 0.5, True, False, mapping=True)
+    loss.backward()
+    # the reference's structure
+    params2, variables2 = fresh()
+    tp = transform_to_frame(params2, 0, True, False)
+    rv = transformed_params2rendervar(params2, tp)
+    ds = transformed_params2depthplussilhouette(params2, curr_data['w2c'], tp)
+    rv['means2D'].retain_grad()
+    im, radius, _ = Renderer(raster_settings=cam)(**rv)
+    depth_sil, _, _ = Renderer(raster_settings=cam)(**ds)
+    depth = depth_sil[0].unsqueeze(0)
+    unc = (depth_sil[2].unsqueeze(0) - depth ** 2).detach()
+    mask = (curr_data['depth'] > 0) & (~torch.isnan(depth)) & (~torch.isnan(unc))
+    l2 = calc_loss(curr_data, im, depth, mask, torch.tile(mask, (3, 1, 1)), True, True, False, False)
+    loss2 = sum(v * weights[k] for k, v in l2.items())
+    loss2.backward()
+    seen = radius > 0
+    variables2['max_2D_radius'][seen] = torch.max(radius[seen].float(), variables2['max_2D_radius'][seen])
+    assert float(loss.detach()) == float(loss2.detach()) and float(wl["loss"].detach()) == float(loss.detach())          # the fused pair's images are bit-identical
+    assert torch.equal(variables['seen'], seen) and torch.equal(variables['max_2D_radius'], variables2['max_2D_radius'])
+    assert float((variables['max_2D_radius'] > 3.0).sum()) > 10
+    for k in ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales'):
+        assert_close(params[k].grad.cpu().numpy(), params2[k].grad.cpu().numpy(), 2e-4, f"get_loss d/d{k}", atol_frac=2e-6)
+    assert_close(variables['means2D'].grad.cpu().numpy(), rv['means2D'].grad.cpu().numpy(), 2e-4, "get_loss means2D.grad", atol_frac=2e-6)
