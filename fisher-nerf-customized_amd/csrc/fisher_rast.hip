@@ -769,6 +769,264 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same front end with the compact scorer records written ONCE, in their final place (the product path of the score-only and
+// out_H record modes).  k_preprocess_views<RC, true> parks every visible splat's {recA, recB} in global memory until its phase C
+// knows the splat's slot, reads them back, and rewrites the list entry: 1.7x the bytes the records need
+// (profiles/r02_n_pmc_all.txt: WRITE_SIZE 1.46 GB against 0.86 GB of records per 64-view step).  Here a batch of 256 survivors is
+//   B   projected (the same arithmetic: fr_preprocess_one), and the visible ones are RANKED IN ORDER with wave ballots: the
+//       survivor list of a workgroup is grouped by view and ascending in the Gaussian index inside a view, so a visible pair's
+//       rank among its view's visible splats -- its slot, monotone in the index -- is the view's running count + the visible
+//       pairs of that view in the lower waves + those in the lower lanes;
+//   park their {recA, recB, list entry, rank} go to LDS (13 dwords x 256, structure of arrays), densely;
+//   C   thread r takes the r-th visible pair of the batch at full lane occupancy: Jacobian rows / polynomial
+//       (fr_fisher_record_one), and writes the 96-byte record to its slot and the 16-byte list entry beside it -- consecutive
+//       threads, consecutive records.
+// No bitmaps, no prefix popcounts, no second pass over the lists.  Records, lists and counts are identical to the other form's.
+template <int RC>
+__global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, FrRecordArgs ra)
+{
+	static_assert(RC != 0, "records modes only");
+	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12] | park[13][FR_THREADS]
+	const int VC = p.VC;
+	uint32_t* hist = fr_dyn_lds;
+	uint32_t* pairs = hist + (size_t)VC * p.T;
+	float* s_wm = (float*)(pairs + FR_THREADS * VC);
+	uint32_t* park = (uint32_t*)(s_wm + 12 * VC);
+	__shared__ uint32_t s_n[FR_VC_MAX];          // visible pairs per view so far = the next slot of the view
+	__shared__ uint32_t s_ref[FR_VC_MAX];
+	__shared__ uint32_t s_ca[FR_VC_MAX * 4];     // phase A: survivors per (view, wave)
+	__shared__ uint32_t s_bv[FR_VC_MAX];         // visible pairs per view of the current batch
+	__shared__ uint32_t s_wtot[4];               // ... per wave
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int v0 = blockIdx.y * VC;
+	const int nv = min(VC, p.V - v0);
+	const uint32_t nblk = gridDim.x;
+	const uint32_t cap = (uint32_t)(FR_THREADS * p.G);
+	for (int t = tid; t < nv * p.T; t += FR_THREADS) hist[t] = 0;
+	const bool has_w2c = p.w2c != nullptr;
+	if (has_w2c) for (int t = tid; t < nv * 12; t += FR_THREADS) s_wm[t] = p.w2c[16 * (size_t)(v0 + t / 12) + (t % 12)];
+	if (tid < FR_VC_MAX) { s_n[tid] = 0; s_ref[tid] = 0; s_bv[tid] = 0; }
+	float vm[16], pm[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const size_t PV = (size_t)nblk * cap;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	__syncthreads();
+	for (int g = 0; g < p.G; g++)
+	{
+		const int i0 = (blockIdx.x * p.G + g) * FR_THREADS;
+		if (i0 >= p.P) break;
+		uint32_t np = 0;
+		// ---- phase A (the tests of k_preprocess_views): near-plane + early frustum test, survivors compacted into `pairs`
+		{
+			const int i = i0 + tid;
+			const bool live = i < p.P;
+			fr_f3 pw = { 0.f, 0.f, 0.f };
+			if (live) pw = fr_f3{ p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+			const bool early = ra.cov_trace != nullptr;
+			float tr = 0.f;
+			if (early && live) tr = ra.cov_trace[i];
+			const float lx = 1.3f * p.tanfovx, ly = 1.3f * p.tanfovy;
+			float wn;
+			{
+				const float c0 = fabsf(vm[0]) + fabsf(vm[1]) + fabsf(vm[2]), c1 = fabsf(vm[4]) + fabsf(vm[5]) + fabsf(vm[6]), c2 = fabsf(vm[8]) + fabsf(vm[9]) + fabsf(vm[10]);
+				const float r0 = fabsf(vm[0]) + fabsf(vm[4]) + fabsf(vm[8]), r1 = fabsf(vm[1]) + fabsf(vm[5]) + fabsf(vm[9]), r2 = fabsf(vm[2]) + fabsf(vm[6]) + fabsf(vm[10]);
+				wn = fmaxf(c0, fmaxf(c1, c2)) * fmaxf(r0, fmaxf(r1, r2));
+			}
+			const float fx2 = 1.02f * wn * p.focal_x * p.focal_x, fy2 = 1.02f * wn * p.focal_y * p.focal_y;
+			const float xmax = (float)(p.gx * FR_BLOCK_X + FR_BLOCK_X), ymax = (float)(p.gy * FR_BLOCK_Y + FR_BLOCK_Y);
+			// The survivor list has to come out in (view, Gaussian index) order: a visible pair's slot is its rank among the
+			// visible pairs of its view, and the keys rely on that rank being monotone in the index (ties of equal depth).  So the
+			// waves do not append with an atomic cursor: every wave counts its survivors per view, the counts are scanned in
+			// (view, wave) order, and each wave then writes at its fixed offsets.
+			uint32_t keepbits = 0;
+			for (int vv = 0; vv < nv; vv++)
+			{
+				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, s_wm + 12 * vv) : pw;
+				const fr_f3 p_view = fr_xform4x3(po, vm);
+				bool keep = live && !(p_view.z <= 0.001f);
+				if (early)
+				{
+					const fr_f4 ph = fr_xform4x4(po, pm);
+					const float p_w = 1.0f / (ph.w + 0.0000001f);
+					const float px = ((ph.x * p_w + 1.0f) * (float)p.W - 1.0f) * 0.5f, py = ((ph.y * p_w + 1.0f) * (float)p.H - 1.0f) * 0.5f;
+					const float iz = 1.0f / p_view.z;
+					const float jx = fminf(fabsf(p_view.x * iz) * 1.001f, lx), jy = fminf(fabsf(p_view.y * iz) * 1.001f, ly);
+					const float kc = fx2 * (1.0f + jx * jx) + fy2 * (1.0f + jy * jy);
+					const float rb = 3.0f * sqrtf(kc * tr * (iz * iz) + 0.7f) + 2.0f;
+					const bool outside = (px + rb < 0.f) || (px - rb > xmax) || (py + rb < 0.f) || (py - rb > ymax);
+					keep = keep && !outside;
+				}
+				keepbits |= (keep ? 1u : 0u) << vv;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+				if (lane == 0) s_ca[vv * 4 + wave] = (uint32_t)__popcll(m);
+			}
+			__syncthreads();
+			// exclusive scan of the 4 nv counts (every wave for itself: lane l holds entry l)
+			uint32_t cnt_l = lane < 4 * nv ? s_ca[lane] : 0u;
+			uint32_t inc = cnt_l;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1)
+			{
+				const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64);
+				if (lane >= d) inc += y;
+			}
+			const uint32_t exc = inc - cnt_l;
+			np = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+			for (int vv = 0; vv < nv; vv++)
+			{
+				const bool keep = (keepbits >> vv) & 1u;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+				const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)exc, vv * 4 + wave);
+				if (keep) pairs[base + (uint32_t)__popcll(m & lt)] = (uint32_t)tid | ((uint32_t)vv << 8);
+			}
+		}
+		__syncthreads();
+		for (uint32_t e0 = 0; e0 < np; e0 += FR_THREADS)
+		{
+			const uint32_t e = e0 + (uint32_t)tid;
+			const bool active = e < np;
+			// ---- phase B: projection of one survivor
+			int i = 0, vv = 0;
+			fr_splat sp;
+			sp.radius = 0;
+			float o = 0.f, cg = 0.f;
+			uint32_t ext = 0;
+			if (active)
+			{
+					const uint32_t pr = pairs[e];
+				i = i0 + (int)(pr & 255u);
+				vv = (int)(pr >> 8);
+				constexpr int PSB = FrPackSize<(RC < 0 ? -RC : RC)>::value;
+				const float4* pk = (const float4*)(ra.packed + (size_t)i * PSB);
+				const float4 t0 = pk[0], t1 = pk[1], t2 = pk[2];
+				const fr_f3 pw = fr_f3{ t0.x, t0.y, t0.z };
+				float c3[6];
+				c3[0] = t0.w; c3[1] = t1.x; c3[2] = t1.y; c3[3] = t1.z; c3[4] = t1.w; c3[5] = t2.x;
+				cg = t2.y + t2.z + t2.w;
+				float wm[12];
+				if (has_w2c)
+				{
+#pragma unroll
+					for (int k = 0; k < 12; k++) wm[k] = s_wm[12 * vv + k];
+				}
+				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+				sp = fr_preprocess_one(po, c3, vm, pm, p.W, p.H, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.gx, p.gy);
+				if (sp.radius > 0) { o = p.opac[i]; ext = fr_alpha_extent(sp.conx, sp.cony, sp.conz, o); }
+			}
+			const bool vis = sp.radius > 0;
+			// ---- ordered ranks.  The list is sorted by (view, index), so is every batch: a visible pair's position among the
+			// batch's visible pairs (`pos`: lower waves + lower lanes) minus the batch's visible pairs of the lower views is its rank
+			// among the batch's visible pairs of ITS view; s_n adds the view's pairs of the earlier batches.
+			const unsigned long long mv = __builtin_amdgcn_ballot_w64(vis);
+			if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(mv);
+			for (int k = 0; k < nv; k++)
+			{
+				const unsigned long long mk = __builtin_amdgcn_ballot_w64(vis && vv == k);
+				if (lane == 0 && mk) atomicAdd(&s_bv[k], (uint32_t)__popcll(mk));
+			}
+			__syncthreads();
+			uint32_t rank = 0, pos = 0, nvis = 0;
+			{
+#pragma unroll
+				for (int w = 0; w < 4; w++) { const uint32_t c = s_wtot[w]; nvis += c; pos += (w < wave) ? c : 0u; }
+				pos += (uint32_t)__popcll(mv & lt);
+			}
+			if (vis)
+			{
+				uint32_t before = 0;
+				for (int k = 0; k < vv; k++) before += s_bv[k];
+				rank = s_n[vv] + pos - before;
+			}
+			__syncthreads();                                        // every rank is taken: s_n and s_bv may change
+			if (tid < nv) { s_n[tid] += s_bv[tid]; s_bv[tid] = 0u; }
+			if (vis)
+			{
+				// tile rectangle: the reference's radius rectangle (rasterizer_impl.cu:70-111) cut down to the tiles the conservative
+				// alpha footprint reaches, exactly as in k_preprocess_views
+				uint32_t rx0 = sp.rect.x0, rx1 = sp.rect.x1, ry0 = sp.rect.y0, ry1 = sp.rect.y1;
+				atomicAdd(&s_ref[vv], (rx1 - rx0) * (ry1 - ry0));
+				{
+					const float hx = __half2float(__ushort_as_half((unsigned short)(ext & 0xffffu)));
+					const float hy = __half2float(__ushort_as_half((unsigned short)(ext >> 16)));
+					if (hx < 0.f) { rx1 = rx0; ry1 = ry0; }
+					else if (hx < 1e30f)
+					{
+						const float inv = 1.0f / (float)FR_BLOCK_X;
+						const int tx0 = (int)floorf((sp.px - hx) * inv), tx1 = (int)floorf((sp.px + hx) * inv) + 1;
+						const int ty0 = (int)floorf((sp.py - hy) * inv), ty1 = (int)floorf((sp.py + hy) * inv) + 1;
+						rx0 = (uint32_t)max((int)rx0, tx0); rx1 = (uint32_t)max((int)rx0, min((int)rx1, tx1));
+						ry0 = (uint32_t)max((int)ry0, ty0); ry1 = (uint32_t)max((int)ry0, min((int)ry1, ty1));
+					}
+				}
+				uint32_t* h = hist + (size_t)vv * p.T;
+				for (uint32_t y = ry0; y < ry1; y++)
+					for (uint32_t x = rx0; x < rx1; x++)
+						atomicAdd(&h[y * p.gx + x], 1u);
+				park[0 * FR_THREADS + pos] = __float_as_uint(sp.px);
+				park[1 * FR_THREADS + pos] = __float_as_uint(sp.py);
+				park[2 * FR_THREADS + pos] = ext;
+				park[3 * FR_THREADS + pos] = __float_as_uint(__builtin_amdgcn_logf(o));
+				park[4 * FR_THREADS + pos] = __float_as_uint(-0.5f * sp.conx);
+				park[5 * FR_THREADS + pos] = __float_as_uint(-sp.cony);
+				park[6 * FR_THREADS + pos] = __float_as_uint(-0.5f * sp.conz);
+				park[7 * FR_THREADS + pos] = __float_as_uint(cg);
+				park[8 * FR_THREADS + pos] = (uint32_t)i;
+				park[9 * FR_THREADS + pos] = fr_as_u32(sp.depth);
+				park[10 * FR_THREADS + pos] = rx0 | (ry0 << 16);
+				park[11 * FR_THREADS + pos] = rx1 | (ry1 << 16);
+				park[12 * FR_THREADS + pos] = rank | ((uint32_t)vv << 16);
+			}
+			__syncthreads();
+			// ---- phase C: the r-th visible pair of the batch
+			if ((uint32_t)tid < nvis)
+			{
+					const int r = tid;
+				float4 ab[2];
+				ab[0] = make_float4(__uint_as_float(park[0 * FR_THREADS + r]), __uint_as_float(park[1 * FR_THREADS + r]),
+				                    __uint_as_float(park[2 * FR_THREADS + r]), __uint_as_float(park[3 * FR_THREADS + r]));
+				ab[1] = make_float4(__uint_as_float(park[4 * FR_THREADS + r]), __uint_as_float(park[5 * FR_THREADS + r]),
+				                    __uint_as_float(park[6 * FR_THREADS + r]), __uint_as_float(park[7 * FR_THREADS + r]));
+				const uint32_t idx = park[8 * FR_THREADS + r];
+				const uint32_t rk = park[12 * FR_THREADS + r];
+				const int cvv = (int)(rk >> 16);
+				const uint32_t slot = blockIdx.x * cap + (rk & 0xffffu);
+				const int v = v0 + cvv;
+				float wm[12];
+#pragma unroll
+				for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * cvv + k] : 0.f;
+				fr_fisher_record_one<(RC < 0 ? -RC : RC), false, (RC < 0)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c,
+				                                                           ra.comp + ((size_t)v * PV + slot) * 6, ab);
+				FrVisEntry en;
+				en.idx = slot; en.depth_bits = park[9 * FR_THREADS + r];          // the keys carry the slot
+				en.xy0 = park[10 * FR_THREADS + r]; en.xy1 = park[11 * FR_THREADS + r];
+				*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)) = *(const uint4*)&en;
+				if constexpr (RC < 0) ra.slot_idx[(size_t)v * PV + slot] = idx;     // (only k_fisher_tile_v3h goes back to the index)
+			}
+			__syncthreads();                                        // park[], s_wtot and s_bv are reused by the next batch
+		}
+	}
+	for (int vv = 0; vv < nv; vv++)
+	{
+		const int v = v0 + vv;
+		uint32_t* cnt = p.tile_cnt + (size_t)v * p.T;
+		const uint32_t* h = hist + (size_t)vv * p.T;
+		for (int t = tid; t < p.T; t += FR_THREADS)
+		{
+			const uint32_t c = h[t];
+			if (c) p.blk_base[((size_t)v * nblk + blockIdx.x) * p.T + t] = atomicAdd(&cnt[t], c);
+		}
+	}
+	if (tid < nv)
+	{
+		const int v = v0 + tid;
+		p.vis_n[(size_t)v * nblk + blockIdx.x] = s_n[tid];
+		if (p.vis_count && s_n[tid]) atomicAdd(&p.vis_count[v], (int)s_n[tid]);
+		if (p.num_rendered && s_ref[tid]) atomicAdd(&p.num_rendered[v], (int)s_ref[tid]);
+	}
+}
 // Key scatter of the multi-view front end: one workgroup per (preprocess workgroup, view), all lanes busy.
 __global__ __launch_bounds__(FR_THREADS) void k_scatter_vis(FrParams p)
 {
@@ -4188,7 +4446,13 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
-		if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+		// compact records: written once, in place, by k_preprocess_views_c (FR_DEBUG_MODE=20 keeps the parking form for A/B runs)
+		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
+		const size_t lds_c = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
+		if (once && plan->form_a) hipLaunchKernelGGL((k_preprocess_views_c<-4>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once) hipLaunchKernelGGL((k_preprocess_views_c<11>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->form_a) hipLaunchKernelGGL((k_preprocess_views<-4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else hipLaunchKernelGGL((k_preprocess_views<11, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);

@@ -314,7 +314,7 @@ class FisherScorer:
             want = (V * PC) if H_inv_per_view else PC
             if H_inv.numel() != want:
                 raise ValueError(f"H_inv has {H_inv.numel()} elements, expected {want}")
-            scores = torch.zeros((V,), dtype=torch.float32, device=d)
+            scores = torch.empty((V,), dtype=torch.float32, device=d)     # every element is written (or the status word says overflow)
         if out_H is not None:
             want = (V * PC) if out_H_per_view else PC
             if out_H.numel() != want or out_H.dtype != torch.float32 or not out_H.is_contiguous() or out_H.device != d:
@@ -327,10 +327,11 @@ class FisherScorer:
             dL_image = _prep(dL_image, d)
             if dL_image.numel() not in (HW3, V * HW3):
                 raise ValueError(f"dL_image has {dL_image.numel()} elements, expected {HW3} or {V * HW3}")
-        vis = torch.zeros((V,), dtype=torch.int32, device=d)
-        nr = torch.zeros((V,), dtype=torch.int32, device=d)
+        # zero-filled / fully written by the library itself (k_zero_many, k_scan_tiles, k_reduce_scores): no fill kernels here
+        vis = torch.empty((V,), dtype=torch.int32, device=d)
+        nr = torch.empty((V,), dtype=torch.int32, device=d)
         n_groups = self.n_streams if (V >= 16 * self.n_streams and V % (8 * self.n_streams) == 0) else 1
-        status = torch.zeros((n_groups, 4), dtype=torch.int32, device=d)
+        status = torch.empty((n_groups, 4), dtype=torch.int32, device=d)
         per = V // n_groups
         cur = torch.cuda.current_stream(d)
         if n_groups > 1 and len(self._side_streams) < n_groups - 1:
