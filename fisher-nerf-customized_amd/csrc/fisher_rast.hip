@@ -4074,6 +4074,236 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_walk(FrParams p, Fr
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// grad_power == 2 through the rasteriser API (the reference's own Fisher loop, gaussian.py:1536-1556: one view, autograd,
+// GaussianRasterizer(backward_power=2)): every leaf the reference accumulates is w = opacity G dL_dalpha times a per-Gaussian row
+// applied to gamma(u) = (ux, uy, ux^2, ux uy, uy^2), u = -conic d (fr_math.h).  k_backward_sq_rows builds the rows ONCE per
+// visible Gaussian (k_fisher_tile_v2<25> rebuilt them per (strip, list chunk): 256 VGPRs, 544 bytes of scratch); the tile
+// kernel is k_backward_lin_walk's walk -- back to front, final_T / n_contrib from the forward pass, the reference's recurrences
+// and the forward's exact arithmetic (fr_expf, IEEE division), no first pass, no list capacity -- with the rows parked beside the
+// candidate: per pair 54 multiply-adds give the 25 leaves, their squares go into per-candidate LDS accumulators (double).
+// (A cheaper form -- sum the twelve second moments of w gamma per splat and take the quadratic forms once per Gaussian -- was
+// built and dropped: a row that is nearly orthogonal to a needle's u-distribution cancels in the quadratic form, 4 of 60 000
+// entries of the `general` test family missed 1e-4 by a factor of 12.)
+#define FR_SQ_ROWS 56                // floats per Gaussian: mean rows 3 x 5, cov3D rows 6 x 3, scale / rotation rows 7 x 3, 1 / opacity^2, pad
+#define FR_SQ_NL 25                  // leaves: mean2D 2, conic 3, colour 3, opacity 1, mean3D 3, cov3D 6, scale 3, rotation 4
+__global__ __launch_bounds__(FR_THREADS) void k_backward_sq_rows(FrParams p, float* __restrict__ rows)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i >= p.P || p.radii[i] <= 0) return;
+	float vm[16], pm[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
+	const fr_f3 po = { p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
+	float c3[6];
+#pragma unroll
+	for (int k = 0; k < 6; k++) c3[k] = p.cov3D[6 * (size_t)i + k];
+	float Rg[3][5], Bg[6][3], Cg[7][3];
+	fr_mean_rows_g(po, c3, vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, p.W, p.H, Rg, Bg, nullptr, nullptr);
+	const fr_f3 sc = { p.scales[3 * (size_t)i], p.scales[3 * (size_t)i + 1], p.scales[3 * (size_t)i + 2] };
+	const fr_f4 q = { p.rots[4 * (size_t)i], p.rots[4 * (size_t)i + 1], p.rots[4 * (size_t)i + 2], p.rots[4 * (size_t)i + 3] };
+	fr_scale_rot_jacobian(sc, p.mod, q, Bg, Cg);
+	float r[FR_SQ_ROWS];
+#pragma unroll
+	for (int a = 0; a < 3; a++)
+#pragma unroll
+		for (int c = 0; c < 5; c++) r[a * 5 + c] = Rg[a][c];
+#pragma unroll
+	for (int a = 0; a < 6; a++)
+#pragma unroll
+		for (int c = 0; c < 3; c++) r[15 + a * 3 + c] = Bg[a][c];
+#pragma unroll
+	for (int a = 0; a < 7; a++)
+#pragma unroll
+		for (int c = 0; c < 3; c++) r[33 + a * 3 + c] = Cg[a][c];
+	const float o = ((const float4*)p.splat)[2 * (size_t)i + 1].y;      // the forward's record {conz, opacity, depth, ext}: the backward ABI carries no opacities
+	r[54] = 1.0f / (o * o); r[55] = 0.f;
+	float4* dst = (float4*)(rows + (size_t)i * FR_SQ_ROWS);
+#pragma unroll
+	for (int k = 0; k < FR_SQ_ROWS / 4; k++) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_backward_sq_walk(FrParams p, FrBwdArgs b, const float* __restrict__ rows)
+{
+	constexpr int EF4 = 3 + FR_SQ_ROWS / 4;      // 17 float4 per parked candidate (odd: sixteen consecutive records cover all LDS banks)
+	__shared__ uint2 s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][64][EF4];
+	__shared__ double s_acc[4][FR_SQ_NL][64];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const uint32_t n = p.tile_cnt[tile];
+	const uint64_t* gk = p.keys + p.tile_off[tile];
+	const float4* splat = (const float4*)p.splat;
+	uint2* wq = s_q[wave];
+	float4 (*ent)[EF4] = s_ent[wave];
+
+	const size_t HW = (size_t)p.H * p.W;
+	const size_t pix = (size_t)p.W * pxy + pxx;
+	const float T_final = inside ? b.final_T[pix] : 0.f;
+	const uint32_t ncontrib = inside ? b.n_contrib[pix] : 0u;
+	float Tc = T_final, last_alpha = 0.f;
+	float accum[3] = { 0.f, 0.f, 0.f }, lastc[3] = { 0.f, 0.f, 0.f }, g[3] = { 0.f, 0.f, 0.f };
+	if (inside) { g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix]; }
+	const float bg_dot = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
+	const float hw = (float)(0.5 * p.W), hh = (float)(0.5 * p.H);
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+	uint32_t nmax = ncontrib;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o, 64); nmax = t > nmax ? t : nmax; }
+	nmax = nmax < n ? nmax : n;
+
+	uint32_t qh = 0, qn = 0;
+	int base = nmax > 0u ? (int)((nmax - 1u) & ~63u) : -64;
+	while (true)
+	{
+		while (qn < 64u && base >= 0)
+		{
+			const uint32_t pos = (uint32_t)base + (uint32_t)lane;
+			bool ov = false;
+			uint32_t id = 0;
+			if (pos < nmax)
+			{
+				id = (uint32_t)gk[pos];
+				const float4 q0 = splat[2 * (size_t)id], q1 = splat[2 * (size_t)id + 1];
+				const uint32_t eb = __float_as_uint(q1.w);
+				const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+				const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+				ov = hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi) && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
+			}
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(lane < 63 ? (om >> (lane + 1)) : 0ull)) & (FR_QCAP - 1)] = make_uint2(id, pos);
+			qn += (uint32_t)__popcll(om);
+			base -= 64;
+		}
+		if (qn == 0) break;
+		const uint32_t m = qn < 64u ? qn : 64u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+		for (int c = 0; c < FR_SQ_NL; c++) s_acc[wave][c][lane] = 0.0;
+		unsigned long long emask = 0ull;
+		uint32_t my_id = 0;
+		if ((uint32_t)lane < m)
+		{
+			const uint2 qe = wq[(qh + lane) & (FR_QCAP - 1)];
+			my_id = qe.x;
+			const float4 q0 = splat[2 * (size_t)my_id], q1 = splat[2 * (size_t)my_id + 1];   // {x, y, conx, cony} {conz, opacity, depth, ext}
+			ent[lane][0] = q0;
+			ent[lane][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(qe.y));
+			ent[lane][2] = make_float4(b.colors[3 * (size_t)my_id], b.colors[3 * (size_t)my_id + 1], b.colors[3 * (size_t)my_id + 2], 0.f);
+			const float4* rsrc = (const float4*)(rows + (size_t)my_id * FR_SQ_ROWS);
+#pragma unroll
+			for (int k = 0; k < FR_SQ_ROWS / 4; k++) ent[lane][3 + k] = rsrc[k];
+			const float4 a = make_float4(q0.x, q0.y, q1.w, __builtin_amdgcn_logf(q1.y));
+			const float4 b4 = make_float4(-0.5f * q0.z, -q0.w, -0.5f * q1.x, 0.f);
+			emask = fr_footprint_mask<16, 4>(a, b4, strip_lo, tile_x0);
+		}
+		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (!inside) mask = 0ull;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
+			if (__float_as_uint(r1.w) >= ncontrib) continue;          // behind the pixel's last contributor (backward.cu:951-957)
+			const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
+			const float dx = r0.x - pfx, dy = r0.y - pfy;
+			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+			if (power > 0.0f || power < r1.z) continue;
+			const float G = fr_expf_inrange(power);
+			const float alpha = fminf(0.99f, o * G);
+			if (alpha < 1.0f / 255.0f) continue;
+			// backward.cu:978-1038
+			Tc = Tc / (1.f - alpha);
+			const float wcol = alpha * Tc;
+			const float rc[3] = { r2.x, r2.y, r2.z };
+			float da = 0.f;
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+			{
+				accum[c] = last_alpha * lastc[c] + (1.f - last_alpha) * accum[c];
+				lastc[c] = rc[c];
+				da += (rc[c] - accum[c]) * g[c];
+			}
+			da *= Tc;
+			last_alpha = alpha;
+			if (bg_dot != 0.f) da += (-T_final / (1.f - alpha)) * bg_dot;
+			const float w = (o * da) * G;                                    // dL_dG * G
+			const float ux = -(cx * dx + cy * dy), uy = -(cy * dx + cz * dy);   // u = -conic d
+			const float uxx = ux * ux, uxy = ux * uy, uyy = uy * uy;
+			double* acc = &s_acc[wave][0][j];
+			// (scheduling fences: without them the compiler forms all the addends before the first ds_add_f64)
+			{
+				const float l0 = w * ux * hw, l1 = w * uy * hh;                                   // dL_dmean2D (backward.cu:1021-1024)
+				const float hq = -0.5f * w;
+				const float l2 = hq * dx * dx, l3 = hq * dx * dy, l4 = hq * dy * dy;               // dL_dconic x, y, w (1026-1029)
+				atomicAdd(acc + 0 * 64, (double)(l0 * l0)); atomicAdd(acc + 1 * 64, (double)(l1 * l1));
+				atomicAdd(acc + 2 * 64, (double)(l2 * l2)); atomicAdd(acc + 3 * 64, (double)(l3 * l3)); atomicAdd(acc + 4 * 64, (double)(l4 * l4));
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			{
+#pragma unroll
+				for (int c = 0; c < 3; c++) { const float l = wcol * g[c]; atomicAdd(acc + (5 + c) * 64, (double)(l * l)); }   // dL_dcolors
+				const float4 rz = ent[j][3 + 13];                                                 // {Cg[6][0..2] tail ..., 1/o^2}: rows[52..55]
+				const float lo = w * w * rz.z;                                                      // dL_dopacity = G dL_dalpha = w / opacity
+				atomicAdd(acc + 8 * 64, (double)lo);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			// the 16 rows: mean 3 x 5, then cov3D 6 x 3 and scale / rotation 7 x 3 over (ux^2, ux uy, uy^2)
+			const float* rf = (const float*)&ent[j][3];
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+			{
+				const float l = w * (rf[r * 5] * ux + rf[r * 5 + 1] * uy + rf[r * 5 + 2] * uxx + rf[r * 5 + 3] * uxy + rf[r * 5 + 4] * uyy);
+				atomicAdd(acc + (9 + r) * 64, (double)(l * l));
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int r = 0; r < 13; r++)
+			{
+				const float l = w * (rf[15 + r * 3] * uxx + rf[15 + r * 3 + 1] * uxy + rf[15 + r * 3 + 2] * uyy);
+				atomicAdd(acc + (12 + r) * 64, (double)(l * l));
+				if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if ((uint32_t)lane < m)
+		{
+			const size_t id = my_id;
+			float a;
+			if ((a = (float)s_acc[wave][0][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id, a);
+			if ((a = (float)s_acc[wave][1][lane]) != 0.f) atomicAdd(b.dL_dmean2D + 3 * id + 1, a);
+			if ((a = (float)s_acc[wave][2][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id, a);
+			if ((a = (float)s_acc[wave][3][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 1, a);
+			if ((a = (float)s_acc[wave][4][lane]) != 0.f) atomicAdd(b.dL_dconic + 4 * id + 3, a);
+#pragma unroll
+			for (int c = 0; c < 3; c++) if ((a = (float)s_acc[wave][5 + c][lane]) != 0.f) atomicAdd(b.dL_dcolors + 3 * id + c, a);
+			if ((a = (float)s_acc[wave][8][lane]) != 0.f) atomicAdd(b.dL_dopacity + id, a);
+#pragma unroll
+			for (int c = 0; c < 3; c++) if ((a = (float)s_acc[wave][9 + c][lane]) != 0.f) atomicAdd(b.dL_dmean3D + 3 * id + c, a);
+#pragma unroll
+			for (int c = 0; c < 6; c++) if ((a = (float)s_acc[wave][12 + c][lane]) != 0.f) atomicAdd(b.dL_dcov3D + 6 * id + c, a);
+#pragma unroll
+			for (int c = 0; c < 3; c++) if ((a = (float)s_acc[wave][18 + c][lane]) != 0.f) atomicAdd(b.dL_dscale + 3 * id + c, a);
+#pragma unroll
+			for (int c = 0; c < 4; c++) if ((a = (float)s_acc[wave][21 + c][lane]) != 0.f) atomicAdd(b.dL_drot + 4 * id + c, a);
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
 // Per Gaussian: the Jacobian chain of backward.cu:276-475,532-583 applied ONCE to the summed u (power 1 only).
 template <bool HAS_SR, bool HAS_SH>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_finish(FrParams p, FrBwdArgs b, float* __restrict__ dL_dsh)
@@ -4232,7 +4462,7 @@ static FrLayout fr_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t ma
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.rgb = o; o = fr_align(o + VP * 12);
 	L.clamped = o; o = fr_align(o + VP * 3);
-	L.packed = o; o = fr_align(o + (size_t)P * 128);     // static records of k_fisher_tile_v2<25> (power-2 backward), written by fr_backward
+	L.packed = o; o = fr_align(o + (size_t)P * 256);     // per-Gaussian leaf rows of the power-2 backward (k_backward_sq_rows: 224 B; k_fisher_tile_v2<25>: 128 B), written by fr_backward
 	L.geom_bytes = o > 0 ? o : 256;
 	o = 0;
 	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
@@ -4645,6 +4875,17 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		else if (sh) hipLaunchKernelGGL((k_backward_finish<false, true>), gp, block, 0, s, p, b, dL_dsh);
 		else hipLaunchKernelGGL((k_backward_finish<false, false>), gp, block, 0, s, p, b, dL_dsh);
 		return fr_check_launch("k_backward_finish");
+	}
+	if (power == 2 && sr && !sh && g->colors_precomp && !g->cov3D_precomp && fr_debug_mode() != 21)
+	{
+		// The diagonal Fisher proxy as the reference's own loop asks for it (gaussian.py:1536-1556: one view, autograd, power 2):
+		// the leaf rows once per visible Gaussian (k_backward_sq_rows), then the walking tile kernel (k_backward_sq_walk).
+		// FR_DEBUG_MODE=21 keeps round 2's all-leaves tile kernel (k_fisher_tile_v2<25>) for A/B runs.
+		float* rows = (float*)((char*)geom_ws + L.packed);           // [P][56] floats of the geometry buffer's 256-byte-per-Gaussian region
+		hipLaunchKernelGGL(k_backward_sq_rows, dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, rows);
+		if ((rc = fr_check_launch("k_backward_sq_rows"))) return rc;
+		hipLaunchKernelGGL(k_backward_sq_walk, dim3(p.T), block, 0, s, p, b, (const float*)rows);
+		return fr_check_launch("k_backward_sq_walk");
 	}
 	if (power == 2 && sr && !sh && g->colors_precomp && !g->cov3D_precomp)
 	{

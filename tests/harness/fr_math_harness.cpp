@@ -148,4 +148,25 @@ void h_scorer_pair_factor(int C, const float* mean, const float* cov3D, const fl
 	}
 }
 
+
+// Leaves of ONE (pixel, Gaussian) pair for w = 1 through the rows over gamma(u), u = -conic d, that the record kernels store
+// (fr_mean_rows_g / fr_scale_rot_jacobian): out[10] = mean3D[3], scale[3], rot[4].  conic3 = the binary32 conic of the forward pass.
+void h_leaves_from_rows_g(const float* mean, const float* cov3D, const float* scale, float mod, const float* rot,
+                          const float* view, const float* proj, int W, int H, float tanfovx, float tanfovy,
+                          const float* conic3, float dx, float dy, float* out)
+{
+	const float focal_y = H / (2.0f * tanfovy);
+	const float focal_x = W / (2.0f * tanfovx);
+	fr_f3 m = { mean[0], mean[1], mean[2] };
+	fr_f3 s = { scale[0], scale[1], scale[2] };
+	fr_f4 q4 = { rot[0], rot[1], rot[2], rot[3] };
+	float Rg[3][5], Bg[6][3], Cg[7][3];
+	fr_mean_rows_g(m, cov3D, view, proj, focal_x, focal_y, tanfovx, tanfovy, W, H, Rg, Bg, nullptr, nullptr);
+	fr_scale_rot_jacobian(s, mod, q4, Bg, Cg);
+	const float ux = -(conic3[0] * dx + conic3[1] * dy), uy = -(conic3[1] * dx + conic3[2] * dy);
+	const float gm[5] = { ux, uy, ux * ux, ux * uy, uy * uy };
+	for (int r = 0; r < 3; r++) out[r] = Rg[r][0] * gm[0] + Rg[r][1] * gm[1] + Rg[r][2] * gm[2] + Rg[r][3] * gm[3] + Rg[r][4] * gm[4];
+	for (int r = 0; r < 7; r++) out[3 + r] = Cg[r][0] * gm[2] + Cg[r][1] * gm[3] + Cg[r][2] * gm[4];
+}
+
 }

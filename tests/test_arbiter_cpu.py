@@ -110,3 +110,55 @@ def test_scorer_record_is_as_well_conditioned_as_the_reference_chain(oracle, har
     assert err_ref < 3e-5
     assert err_g < 3e-5 and err_g < 3 * err_ref + 1e-6
     assert err_d > 1e-4
+
+
+def test_rows_over_gamma_u_give_the_reference_leaves(oracle, harness):
+    """fr_mean_rows_g / fr_scale_rot_jacobian (what every record kernel stores: k_fisher_tile_v3h, k_backward_sq_rows) applied to
+    gamma(u) = (ux, uy, ux^2, ux uy, uy^2), u = -conic d, against the reference's per-pair chain evaluated exactly (arbiter build of
+    orc_pair_leaves, backward.cu:1016-1090 -> 276-475, 532-583): mean, scale and rotation leaves of random splats at random
+    offsets inside their footprint."""
+    cf, cd = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    pf = lambda x: x.ctypes.data_as(cf)
+    pd = lambda x: x.ctypes.data_as(cd)
+    L64 = oracle.lib64()
+    from scenes import random_scene
+    W, H = 96, 64
+    w2c = np.eye(4, dtype=np.float32)
+    w2c[:3, :3] = np.array([[0.8, 0, 0.6], [0, 1, 0], [-0.6, 0, 0.8]], np.float32)
+    w2c[:3, 3] = [0.1, 0.05, 0.3]
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), w2c)
+    view = np.ascontiguousarray(cam.viewmatrix, np.float32); proj = np.ascontiguousarray(cam.projmatrix, np.float32)
+    rng = np.random.default_rng(4)
+    errs = []
+    for trial in range(300):
+        sc = random_scene(1, 300 + trial, zmin=0.4, zmax=5.0, spread=1.5, scale=0.15)
+        if trial % 3 == 0:
+            sc["scales"] = (sc["scales"] * np.array([[8.0, 1.0, 0.15]], np.float32)).astype(np.float32)     # needles
+        fwd = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+        if fwd["radii"][0] == 0:
+            continue
+        con = fwd["conic_opacity"][0].astype(np.float64)
+        ev, evec = np.linalg.eigh(np.array([[con[0], con[1]], [con[1], con[2]]]))
+        if ev.min() <= 0:
+            continue
+        th, pw = rng.uniform(0, 2 * np.pi), rng.uniform(0.2, 4.0)
+        d = evec @ (np.sqrt(2 * pw) * np.array([np.cos(th), np.sin(th)]) / np.sqrt(ev))
+        dx, dy = np.float32(d[0]), np.float32(d[1])
+        out = np.zeros(10, np.float32)
+        c32 = np.ascontiguousarray(fwd["conic_opacity"][0, :3], np.float32)
+        harness.h_leaves_from_rows_g(pf(sc["means3D"]), pf(fwd["cov3D"]), pf(sc["scales"]), ctypes.c_float(1.0), pf(sc["rotations"]), pf(view), pf(proj),
+                                     ctypes.c_int(W), ctypes.c_int(H), ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), pf(c32),
+                                     ctypes.c_float(float(dx)), ctypes.c_float(float(dy)), pf(out))
+        want = np.zeros(11)
+        f64 = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).astype(np.float64))
+        L64.orc_pair_leaves(pd(f64(sc["means3D"][0])), pd(f64(fwd["cov3D"][0])), pd(f64(sc["scales"][0])), ctypes.c_double(1.0), pd(f64(sc["rotations"][0])),
+                            pd(f64(view)), pd(f64(proj)), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_double(cam.tanfovx), ctypes.c_double(cam.tanfovy),
+                            pd(f64(fwd["conic_opacity"][0])), ctypes.c_double(float(dx)), ctypes.c_double(float(dy)), ctypes.c_double(1.0), pd(want))
+        ref = np.concatenate([want[0:3], want[4:11]])
+        for lo, hi in ((0, 3), (3, 6), (6, 10)):                # per leaf group: against the group's largest entry
+            scale = np.abs(ref[lo:hi]).max()
+            if scale > 0:
+                errs.append(np.abs(out[lo:hi] - ref[lo:hi]).max() / scale)
+    errs = np.asarray(errs)
+    assert len(errs) > 400
+    assert np.median(errs) < 3e-6 and errs.max() < 5e-4, (float(np.median(errs)), float(errs.max()))

@@ -104,10 +104,23 @@ def test_backward_parity(runs, oracle, gpu, case, power):
     dL = rng.normal(size=(3, H, W)).astype(np.float32) if power == 1 else np.full((3, H, W), 1e-3, np.float32)
     gw = oracle.rasterize_backward(cam, want, dL, power)
     gg = hip_backward(gpu, cam, got, dL, power)
-    for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations")
+    if power == 2:
+        # the arbiter (the oracle's statements in binary64 on the same contributor sets): a Gaussian whose reference chain is
+        # itself off by r > 0 in binary32 (near-plane giants of `general`: up to 1.2e-4) gets (1e-4 + 2 r) instead of 1e-4
+        w64 = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"],
+                                       rotations=sc["rotations"], decisions=want)
+        ga = oracle.rasterize_backward(cam, w64, dL, power)
+    for n in names:
         # power 1 sums signed terms (cancellation): compare against the tensor's scale; power 2 sums squares: 1e-4 relative
         if power == 2:
-            assert_close(gg[n], gw[n], 1e-4, f"{case}/{n}", atol_frac=1e-7)
+            o, a = gw[n].astype(np.float64).reshape(gw[n].shape[0], -1), ga[n].reshape(gw[n].shape[0], -1)
+            big = np.abs(a) > 1e-7 * np.abs(a).max()
+            r = np.where(big, np.abs(o - a) / np.maximum(np.abs(a), 1e-300), 0.0).max(axis=1, keepdims=True)
+            tol = (1e-4 + 2.0 * r) * np.abs(o) + 1e-7 * np.abs(o).max()
+            bad = np.abs(gg[n].astype(np.float64).reshape(o.shape) - o) > tol
+            assert not bad.any(), (f"{case}/{n}", int(bad.sum()), float((np.abs(gg[n].reshape(o.shape) - o) / np.maximum(tol, 1e-300)).max()))
+            assert (r > 2e-5).mean() < 0.02
         else:
             assert_close(gg[n], gw[n], 1e-4, f"{case}/{n}", atol_frac=2e-5)
     assert gg["dL_dsh"].shape == (sc["means3D"].shape[0], 0, 3)
