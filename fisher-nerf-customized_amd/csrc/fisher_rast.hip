@@ -500,8 +500,9 @@ struct FrRecordArgs {
 	// slot = projection workgroup * (256 G) + rank of the Gaussian among the workgroup's visible ones of that view -- monotone in
 	// the Gaussian index, so keys that carry the slot sort exactly like keys that carry the index, and a workgroup's records of a
 	// view form one dense run instead of being strewn over [P]
-	float4* comp;                // [V][PV][6], PV = workgroups * 256 G
-	uint32_t* slot_idx;          // [V][PV]: slot -> Gaussian index (k_fisher_tile_v3h flushes by index)
+	float4* comp;                // [V][PV][stride], PV = workgroups * 256 G
+	uint32_t* slot_idx;          // [V][PV]: slot -> Gaussian index (k_fisher_tile_v3h / _v3g flush by index)
+	int stride;                  // float4 per compact record: 6 ({recA, recB} + 4), or 7 / 13 in the general out_H form (fr_fisher_record_general)
 };
 // floats per Gaussian of the packed static record (k_pack_static): {mean 3, cov3D 6, rgb 3, (scale 3, rot 4), H_inv C}
 template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
@@ -510,6 +511,12 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c,
                                                      float4* out6 = nullptr, const float4* ab_src = nullptr);
+// float4 per compact record of a front-end mode: AF 0 = score form, 1 = A-form of k_fisher_tile_v3h, 2 = general out_H form
+template <int C, int AF> struct FrRecStride { static constexpr int value = AF == 2 ? (C >= 11 ? 13 : 7) : 6; };
+template <int C>
+__device__ __forceinline__ void fr_fisher_record_general(const FrParams& p, const float* __restrict__ packed, int v, uint32_t id,
+                                                         const float* vm, const float* pm, const float* wm, bool has_w2c,
+                                                         float4* out, const float4* ab_src);
 
 // ---------------------------------------------------------------------------------------------------------
 // Multi-view front end of the Fisher path (same camera, one rigid transform per candidate view).
@@ -783,10 +790,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 //       (fr_fisher_record_one), and writes the 96-byte record to its slot and the 16-byte list entry beside it -- consecutive
 //       threads, consecutive records.
 // No bitmaps, no prefix popcounts, no second pass over the lists.  Records, lists and counts are identical to the other form's.
-template <int RC>
+template <int C, int AF>
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, FrRecordArgs ra)
 {
-	static_assert(RC != 0, "records modes only");
+	static_assert((C == 4 || C == 11) && AF >= 0 && AF <= 2 && !(AF == 1 && C != 4), "records modes: score form, A-form (4 columns), general out_H form");
+	constexpr int RS = FrRecStride<C, AF>::value;     // float4 per compact record
 	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12] | park[13][FR_THREADS]
 	const int VC = p.VC;
 	uint32_t* hist = fr_dyn_lds;
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 					const uint32_t pr = pairs[e];
 				i = i0 + (int)(pr & 255u);
 				vv = (int)(pr >> 8);
-				constexpr int PSB = FrPackSize<(RC < 0 ? -RC : RC)>::value;
+				constexpr int PSB = FrPackSize<C>::value;
 				const float4* pk = (const float4*)(ra.packed + (size_t)i * PSB);
 				const float4 t0 = pk[0], t1 = pk[1], t2 = pk[2];
 				const fr_f3 pw = fr_f3{ t0.x, t0.y, t0.z };
@@ -997,13 +1005,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				float wm[12];
 #pragma unroll
 				for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * cvv + k] : 0.f;
-				fr_fisher_record_one<(RC < 0 ? -RC : RC), false, (RC < 0)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c,
-				                                                           ra.comp + ((size_t)v * PV + slot) * 6, ab);
+				float4* rec_out = ra.comp + ((size_t)v * PV + slot) * RS;
+				if constexpr (AF == 2) fr_fisher_record_general<C>(p, ra.packed, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
+				else fr_fisher_record_one<C, false, (AF == 1)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
 				FrVisEntry en;
 				en.idx = slot; en.depth_bits = park[9 * FR_THREADS + r];          // the keys carry the slot
 				en.xy0 = park[10 * FR_THREADS + r]; en.xy1 = park[11 * FR_THREADS + r];
 				*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)) = *(const uint4*)&en;
-				if constexpr (RC < 0) ra.slot_idx[(size_t)v * PV + slot] = idx;     // (only k_fisher_tile_v3h goes back to the index)
+				if constexpr (AF != 0) ra.slot_idx[(size_t)v * PV + slot] = idx;    // (the out_H kernels go back to the index)
 			}
 			__syncthreads();                                        // park[], s_wtot and s_bv are reused by the next batch
 		}
@@ -2663,6 +2672,51 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	if (out6) { out6[0] = ab_src[0]; out6[1] = ab_src[1]; }              // compact record: {recA, recB} travel with the coefficients (loaded late: fewer live registers)
 }
 
+// The general out_H record (k_fisher_tile_v3g: 11 columns and / or a per-pixel upstream-gradient image): {recA, recB} and
+//   q[0..14] the three mean rows over gamma(u) (fr_mean_rows_g)   q[15] 1 / opacity^2   q[16..18] r, g, b   q[19] 0
+//   C = 11:  q[20..40] the seven scale / rotation rows over (ux^2, ux uy, uy^2)   q[41..43] 0
+// = 7 float4 at C = 4, 13 at C = 11 (odd strides: sixteen consecutive parked records cover all LDS banks).
+template <int C>
+__device__ __forceinline__ void fr_fisher_record_general(const FrParams& p, const float* __restrict__ packed, int v, uint32_t id,
+                                                         const float* vm, const float* pm, const float* wm, bool has_w2c,
+                                                         float4* out, const float4* ab_src)
+{
+	constexpr int PS = FrPackSize<C>::value;
+	constexpr bool SR = C >= 11;
+	(void)v;
+	float gsv[PS];
+	const float4* pk = (const float4*)(packed + (size_t)id * PS);
+#pragma unroll
+	for (int q = 0; q < PS / 4; q++) { const float4 t4 = pk[q]; gsv[4 * q] = t4.x; gsv[4 * q + 1] = t4.y; gsv[4 * q + 2] = t4.z; gsv[4 * q + 3] = t4.w; }
+	const fr_f3 pw = { gsv[0], gsv[1], gsv[2] };
+	const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
+	float Rg[3][5];
+	float Bg[6][3];
+	// IEEE division (not v_rcp_f32): these records feed per-ENTRY outputs (1e-4 per element, near-plane splats included)
+	fr_mean_rows_g<false>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, p.W, p.H, Rg, SR ? Bg : nullptr, nullptr, nullptr);
+	const float opacity = p.opac[id];
+	const float inv_o = 1.0f / opacity;
+	out[2] = make_float4(Rg[0][0], Rg[0][1], Rg[0][2], Rg[0][3]);
+	out[3] = make_float4(Rg[0][4], Rg[1][0], Rg[1][1], Rg[1][2]);
+	out[4] = make_float4(Rg[1][3], Rg[1][4], Rg[2][0], Rg[2][1]);
+	out[5] = make_float4(Rg[2][2], Rg[2][3], Rg[2][4], inv_o * inv_o);
+	out[6] = make_float4(gsv[9], gsv[10], gsv[11], 0.f);
+	if constexpr (SR)
+	{
+		const fr_f3 sc = { gsv[12], gsv[13], gsv[14] };
+		const fr_f4 qr = { gsv[15], gsv[16], gsv[17], gsv[18] };
+		float Cg[7][3];
+		fr_scale_rot_jacobian(sc, p.mod, qr, Bg, Cg);
+		out[7] = make_float4(Cg[0][0], Cg[0][1], Cg[0][2], Cg[1][0]);
+		out[8] = make_float4(Cg[1][1], Cg[1][2], Cg[2][0], Cg[2][1]);
+		out[9] = make_float4(Cg[2][2], Cg[3][0], Cg[3][1], Cg[3][2]);
+		out[10] = make_float4(Cg[4][0], Cg[4][1], Cg[4][2], Cg[5][0]);
+		out[11] = make_float4(Cg[5][1], Cg[5][2], Cg[6][0], Cg[6][1]);
+		out[12] = make_float4(Cg[6][2], 0.f, 0.f, 0.f);
+	}
+	out[0] = ab_src[0]; out[1] = ab_src[1];
+}
+
 // Stand-alone form of phase C of k_preprocess_views, for the single-view front end (images beyond FR_MAX_LDS_TILES tiles,
 // visibility from radii) -- or over the compact lists (LIST).  Needs the projection only, not the keys.
 template <int C, bool LIST, bool FORM_A>
@@ -3217,9 +3271,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 // The stream / chunk skeleton of k_fisher_tile_v3 for one pass of one wave; NQ = float4 of recq parked per candidate.
 // body(m, id, emask) runs once per chunk of m <= 64 candidates: lane l < m holds candidate l (its index `id`, its footprint
 // `emask` over the wave's pixels) and has parked its record at ent[l]; the body sets `done` for finished pixels.
-template <int BW, int BH, int NQ, class Body>
+template <int BW, int BH, int NQ, class Body, int EF4 = FR_ENT_F4>
 __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, uint32_t n, const float4* __restrict__ rec, size_t sA,
-                                              const float4* __restrict__ rq, size_t sQ, uint32_t* wq, float4 (*ent)[FR_ENT_F4],
+                                              const float4* __restrict__ rq, size_t sQ, uint32_t* wq, float4 (*ent)[EF4],
                                               int lane, float strip_lo, float tile_x0, bool& done, Body body)
 {
 	const float strip_hi = strip_lo + (float)(BH - 1), tile_x1 = tile_x0 + (float)(BW - 1);
@@ -3398,6 +3452,146 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 			}
 			__builtin_amdgcn_wave_barrier();
 		});
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_fisher_tile_v3h generalised: NC = 4 or 11 columns [mean xyz | opacity | scale xyz | rot rxyz] and, with IMG, a per-pixel
+// upstream gradient z = dL_dpix[3] (the `im.backward(gradient=z)` probes of the POp-GS estimators, gaussian_object.py:2088-2098)
+// instead of one constant: GaussianObjectSLAM.compute_Hessian / compute_H_train and the probes on the record machinery.
+// With z the colour sum cg of a splat becomes cgz = z . rgb per pair, X = z . (C_final + T_final bg), and nothing else
+// changes: dL_dalpha_i = T_i cgz_i - (X - Cgz_<=i) b_i.  Same two front-to-back passes, per-candidate double accumulators in LDS.
+// Replaces k_fisher_tile_v2<11, false, true> (199 VGPRs, a Jacobian chain per tile instance) on these paths.
+template <int NC, bool IMG>
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFisherArgs f)
+{
+	constexpr int NQ = NC >= 11 ? 11 : 5;          // float4 of the record behind {recA, recB}
+	constexpr int EF4 = 2 + NQ;
+	__shared__ uint32_t s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][64][EF4];
+	__shared__ double s_acc[4][NC][64];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t bx0 = tx * FR_BLOCK_X, by0 = ty * FR_BLOCK_Y + (uint32_t)wave * 4u;
+	const uint32_t pxx = bx0 + (uint32_t)(lane & 15), pxy = by0 + (uint32_t)(lane >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* rec = f.recA + (size_t)v * f.ab_view;
+	const float4* rq = f.recQ + (size_t)v * f.q_view;
+	const size_t sA = (size_t)f.ab_stride, sQ = (size_t)f.q_stride;
+	const uint32_t* slot_idx = f.slot_idx ? f.slot_idx + (size_t)v * f.slot_view : nullptr;
+	uint32_t* wq = s_q[wave];
+	float4 (*ent)[EF4] = s_ent[wave];
+	double (*acc)[64] = s_acc[wave];
+	const float strip_lo = (float)by0, tile_x0 = (float)bx0;
+	// the pixel's upstream gradient
+	float z0 = 1.f, z1 = 1.f, z2 = 1.f;
+	if constexpr (IMG)
+	{
+		const size_t HW = (size_t)p.H * p.W, pix = (size_t)p.W * pxy + pxx;
+		const float* gi = f.dL_img + (size_t)v * f.dL_stride;
+		z0 = inside ? gi[pix] : 0.f; z1 = inside ? gi[HW + pix] : 0.f; z2 = inside ? gi[2 * HW + pix] : 0.f;
+	}
+
+	// ---- pass 1: X = z . (C_final + T_final bg)
+	float T = 1.0f;
+	double Cg = 0.0;
+	bool done = !inside;
+	auto pass1 = [&](uint32_t, uint32_t, unsigned long long emask) {
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (done) mask = 0ull;
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 a4 = ent[j][0], b44 = ent[j][1];
+			const fr_v4f a = { a4.x, a4.y, a4.z, a4.w }, b4 = { b44.x, b44.y, b44.z, b44.w };
+			const FrPairAlpha g = fr_pair_alpha(a, b4, pfx, pfy);
+			float cgz = b44.w;
+			if constexpr (IMG) { const float4 c = ent[j][2 + 4]; cgz = z0 * c.x + z1 * c.y + z2 * c.z; }
+			bool con;
+			if (fr_prefix_update(g, cgz, T, Cg, con)) { mask = 0ull; done = true; }
+		}
+	};
+	fr_strip_pass<16, 4, NQ, decltype(pass1), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done, pass1);
+	const float bgz = IMG ? (z0 * p.bg[0] + z1 * p.bg[1] + z2 * p.bg[2]) : (p.bg[0] + p.bg[1] + p.bg[2]);
+	const double X = Cg + (double)(T * bgz);
+
+	// ---- pass 2: the squares
+	T = 1.0f; Cg = 0.0;
+	done = !inside;
+	const float dL2 = IMG ? 1.0f : f.dL * f.dL;
+	float* dst = f.out_H + (size_t)v * f.outH_stride;
+	auto pass2 = [&](uint32_t m, uint32_t my_id, unsigned long long emask) {
+#pragma unroll
+		for (int c = 0; c < NC; c++) acc[c][lane] = 0.0;
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (done) mask = 0ull;
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 a4 = ent[j][0], b44 = ent[j][1];
+			const fr_v4f a = { a4.x, a4.y, a4.z, a4.w }, b4 = { b44.x, b44.y, b44.z, b44.w };
+			const FrPairAlpha g = fr_pair_alpha(a, b4, pfx, pfy);
+			float cgz = b44.w;
+			if constexpr (IMG) { const float4 c = ent[j][2 + 4]; cgz = z0 * c.x + z1 * c.y + z2 * c.z; }
+			const float T_i = T;
+			bool con;
+			const bool kill = fr_prefix_update(g, cgz, T, Cg, con);
+			if (con)
+			{
+				const float bi = 1.0f / g.om1;
+				const float dLda = T_i * cgz - (float)(X - Cg) * bi;             // backward.cu:1000-1016 with the suffix written as X - prefix
+				const float w = g.a_un * dLda;
+				const float w2 = w * w;
+				const float dx = g.dx, dy = g.dy;
+				const float u0 = b4.x * dx + (b4.x * dx + b4.y * dy);            // u = -conic d
+				const float u1 = 2.0f * (b4.z * dy) + b4.y * dx;
+				const float u2 = u0 * u0, u3 = u0 * u1, u4 = u1 * u1;
+				const float4 q0 = ent[j][2], q1 = ent[j][3], q2 = ent[j][4], q3 = ent[j][5];
+				const float l0 = q0.x * u0 + q0.y * u1 + q0.z * u2 + q0.w * u3 + q1.x * u4;
+				const float l1 = q1.y * u0 + q1.z * u1 + q1.w * u2 + q2.x * u3 + q2.y * u4;
+				const float l2 = q2.z * u0 + q2.w * u1 + q3.x * u2 + q3.y * u3 + q3.z * u4;
+				atomicAdd(&acc[0][j], (double)(w2 * (l0 * l0))); atomicAdd(&acc[1][j], (double)(w2 * (l1 * l1)));
+				atomicAdd(&acc[2][j], (double)(w2 * (l2 * l2))); atomicAdd(&acc[3][j], (double)(w2 * q3.w));
+				if constexpr (NC >= 11)
+				{
+					__builtin_amdgcn_sched_barrier(0);
+					const float* cf = (const float*)&ent[j][2 + 5];              // seven rows x 3 over (ux^2, ux uy, uy^2)
+#pragma unroll
+					for (int r = 0; r < 7; r++)
+					{
+						const float l = cf[3 * r] * u2 + cf[3 * r + 1] * u3 + cf[3 * r + 2] * u4;
+						atomicAdd(&acc[4 + r][j], (double)(w2 * (l * l)));
+					}
+				}
+			}
+			if (kill) { mask = 0ull; done = true; }
+		}
+		__builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own ds_add instructions have retired
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// flush: consecutive lanes on consecutive columns of one Gaussian (compact records: the candidate's slot back to its index)
+		const uint32_t real_id = (slot_idx && (uint32_t)lane < m) ? slot_idx[my_id] : my_id;
+#pragma unroll 1
+		for (int i = 0; i < NC; i++)
+		{
+			const int flat = i * 64 + lane;
+			const int e = flat / NC, c = flat - e * NC;
+			const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)real_id);
+			const float a = ((uint32_t)e < m) ? (float)acc[c][e] * dL2 : 0.f;
+			if (a != 0.f) atomicAdd(dst + (size_t)id_e * NC + c, a);
+		}
+		__builtin_amdgcn_wave_barrier();
+	};
+	fr_strip_pass<16, 4, NQ, decltype(pass2), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done, pass2);
 }
 
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
@@ -4630,7 +4824,7 @@ struct FrJoinGuard {
 
 // Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
 // k_preprocess_views; with the single-view front end, k_fisher_records after k_scatter_keys, beside the sorts, on the second side stream).
-struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; bool skip_pack = false; };   // skip_pack: a view group after the first (the packed static records are per call)     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
+struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; bool skip_pack = false; bool general = false; };   // general: out_H records of k_fisher_tile_v3g   // skip_pack: a view group after the first (the packed static records are per call)     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
 template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed, float* __restrict__ cov_trace);
 template <int C, bool LIST, bool FORM_A> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
 
@@ -4672,16 +4866,18 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	{
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 2 * (size_t)p.VC * 8 * (size_t)p.G) * 4;
-		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr };
+		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 6 };
 		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
 		// compact records: written once, in place, by k_preprocess_views_c (FR_DEBUG_MODE=20 keeps the parking form for A/B runs)
 		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
 		const size_t lds_c = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
-		if (once && plan->form_a) hipLaunchKernelGGL((k_preprocess_views_c<-4>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
-		else if (once && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
-		else if (once) hipLaunchKernelGGL((k_preprocess_views_c<11>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		if (once && plan->general && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 2>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->general) hipLaunchKernelGGL((k_preprocess_views_c<11, 2>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->form_a) hipLaunchKernelGGL((k_preprocess_views_c<4, 1>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 0>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once) hipLaunchKernelGGL((k_preprocess_views_c<11, 0>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->form_a) hipLaunchKernelGGL((k_preprocess_views<-4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
@@ -5062,7 +5258,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	const size_t VPV = (size_t)V * (L.PV > (size_t)P ? L.PV : (size_t)P);
 	L.splat = o; o = fr_align(o + VPV * sizeof(FrSplat));
 	// dense: [V][P] x 64 B {12 polynomial coefficients + k3, or A'[15], 1/o^2}; compact: [V][PV] x 96 B {recA, recB, the same}
-	L.recq = o; o = fr_align(o + VPV * 96);
+	L.recq = o; o = fr_align(o + VPV * (columns == 11 ? 208 : 112));     // compact: 96 B (score form, A-form), 112 / 208 B (general out_H form, 4 / 11 columns)
 	L.slot_idx = o; o = fr_align(o + VPV * 4);
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.cov_trace = o; o = fr_align(o + (size_t)P * 4);
@@ -5131,6 +5327,27 @@ static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, hipS
 		(void)hipEventRecord(ev0, s);
 	}
 	hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	if (g_prof_on)
+	{
+		(void)hipEventRecord(ev1, s);
+		g_prof_events.push_back(std::make_pair(ev0, ev1));
+	}
+}
+
+// the other out_H modes on records: 11 columns and / or an upstream-gradient image
+static void fr_launch_fisher_v3g(FrParams& p, FrFisherArgs f, int columns, bool img, hipStream_t s)
+{
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (g_prof_on)
+	{
+		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+		(void)hipEventRecord(ev0, s);
+	}
+	dim3 grid(p.T * p.V), block(FR_THREADS);
+	if (columns == 11 && img) hipLaunchKernelGGL((k_fisher_tile_v3g<11, true>), grid, block, 0, s, p, f);
+	else if (columns == 11) hipLaunchKernelGGL((k_fisher_tile_v3g<11, false>), grid, block, 0, s, p, f);
+	else if (img) hipLaunchKernelGGL((k_fisher_tile_v3g<4, true>), grid, block, 0, s, p, f);
+	else hipLaunchKernelGGL((k_fisher_tile_v3g<4, false>), grid, block, 0, s, p, f);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);
@@ -5227,19 +5444,26 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	const bool v3 = fc->H_inv && !fc->out_H && !fc->dL_dpix_image && f.debug_mode != 1 && f.debug_mode != 9;
 	// the diagonal itself (out_H, no H_inv, 4 columns, constant upstream gradient): records + two front-to-back passes
 	const bool v3h = !fc->H_inv && fc->out_H && !fc->dL_dpix_image && fc->columns == 4 && f.debug_mode != 1 && f.debug_mode != 9;
+	// the other out_H modes (11 columns and / or a per-view upstream-gradient image: GaussianObjectSLAM, the POp-GS probes) on
+	// records too, through the multi-view front end; FR_DEBUG_MODE=22 keeps round 2's two-pass kernel (k_fisher_tile_v2) for A/B runs
+	const bool multi_fe = p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES;
+	const bool v3g = !fc->H_inv && fc->out_H && !v3h && multi_fe && !g->cov3D_precomp && f.debug_mode != 1 && f.debug_mode != 9 && f.debug_mode != 22 && f.debug_mode != 19;
 	FrScorerPlan plan;
 	plan.form_a = v3h;
+	plan.general = v3g;
 	plan.columns = fc->columns;
 	plan.ra.H_inv = fc->H_inv; plan.ra.hinv_stride = fc->H_inv_view_stride;
 	plan.ra.packed = (const float*)(ws + L.packed); plan.ra.recq = (float4*)(ws + L.recq);
 	// compact records with the multi-view front end (the same condition fr_bin_pipeline uses for it); FR_DEBUG_MODE=19: dense (A/B runs)
-	const bool compact = (v3 || v3h) && p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES && f.debug_mode != 19;
+	const bool compact = (v3 || v3h || v3g) && multi_fe && f.debug_mode != 19;
+	const int rstride = v3g ? (fc->columns == 11 ? 13 : 7) : 6;
 	plan.ra.comp = compact ? (float4*)(ws + L.recq) : nullptr;
-	plan.ra.slot_idx = (compact && v3h) ? (uint32_t*)(ws + L.slot_idx) : nullptr;
+	plan.ra.stride = rstride;
+	plan.ra.slot_idx = (compact && (v3h || v3g)) ? (uint32_t*)(ws + L.slot_idx) : nullptr;
 	if (compact)
 	{
-		f.recA = plan.ra.comp; f.ab_view = (long long)L.PV * 6; f.ab_stride = 6;
-		f.recQ = plan.ra.comp + 2; f.q_view = (long long)L.PV * 6; f.q_stride = 6;
+		f.recA = plan.ra.comp; f.ab_view = (long long)L.PV * rstride; f.ab_stride = rstride;
+		f.recQ = plan.ra.comp + 2; f.q_view = (long long)L.PV * rstride; f.q_stride = rstride;
 		f.slot_idx = plan.ra.slot_idx; f.slot_view = (long long)L.PV;
 	}
 	else
@@ -5297,7 +5521,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		pl.skip_pack = gi > 0;
 		if (pl.ra.hinv_stride) pl.ra.H_inv = plan.ra.H_inv + (size_t)v0 * plan.ra.hinv_stride;
 		pl.ra.recq = plan.ra.recq + (size_t)v0 * rec_view * 4;
-		if (pl.ra.comp) pl.ra.comp = plan.ra.comp + (size_t)v0 * L.PV * 6;
+		if (pl.ra.comp) pl.ra.comp = plan.ra.comp + (size_t)v0 * L.PV * rstride;
 		if (pl.ra.slot_idx) pl.ra.slot_idx = plan.ra.slot_idx + (size_t)v0 * L.PV;
 		FrFisherArgs fg = f;
 		fg.recA = f.recA + (size_t)v0 * f.ab_view; fg.recQ = f.recQ + (size_t)v0 * f.q_view;
@@ -5307,7 +5531,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		if (f.out_H && f.outH_stride) fg.out_H = f.out_H + (size_t)v0 * f.outH_stride;
 		if (f.dL_img && f.dL_stride) fg.dL_img = f.dL_img + (size_t)v0 * f.dL_stride;
 
-		if ((rc = fr_bin_pipeline(pg, g, s, (v3 || v3h) ? &pl : nullptr))) return rc;
+		if ((rc = fr_bin_pipeline(pg, g, s, (v3 || v3h || v3g) ? &pl : nullptr))) return rc;
 		if (use_side)
 		{
 			if (!front_done[gi] && hipEventCreateWithFlags(&front_done[gi], hipEventDisableTiming) != hipSuccess)
@@ -5318,6 +5542,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		}
 		if (v3) fr_launch_fisher_v3(pg, fg, pl.ra.recq, ts);
 		else if (v3h) fr_launch_fisher_v3h(pg, fg, pl.ra.recq, ts);
+		else if (v3g) fr_launch_fisher_v3g(pg, fg, fc->columns, fc->dL_dpix_image != nullptr, ts);
 		else if (fc->columns == 4) fr_launch_fisher<4>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
 		else fr_launch_fisher<11>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
 		if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
