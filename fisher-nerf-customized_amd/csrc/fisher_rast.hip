@@ -3124,6 +3124,204 @@ __device__ __forceinline__ unsigned long long fr_footprint_mask(const float4& a,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_fisher_tile_v3 with a ROLLING WINDOW of two chunks (experiment, FR_DEBUG_MODE=24; NOT the default).  In k_fisher_tile_v3 the
+// wave re-converges after every chunk of 64 candidates, so every chunk costs as many walk iterations as its busiest pixel-lane has
+// candidates: 7.48 M wave-level iterations per 64-view step where an unsynchronised walk would need 4.5 M (45 % of the lane slots
+// do work).  Here two chunks of 48 candidates are resident in LDS (96 record slots = 32 KiB per workgroup: still five workgroups
+// per CU -- a 128-slot window costs 17 % for the occupancy it loses, measured by padding k_fisher_tile_v3's LDS); a lane that has
+// walked its bits of the older chunk goes straight on to the younger one, and the wave only waits until EVERY lane has left the
+// older chunk, whose slots then take the next 48 candidates.  Measured (profiles/r03_f_window_walk.txt): 5.69 M iterations
+// (-24 %, as a simulation on the oracle's contributor lists predicted), scores bit-identical -- and 1.07 ms against 0.99 ms: the
+// move to the younger chunk costs 8 vector instructions on most iterations (some lane leaves the older chunk nearly every
+// iteration), the loop has three scalar branches where the chunk-synchronous one has a single exec-masked back edge, and a
+// third more chunks are set up (48 instead of 64 candidates each).  Kept for A/B runs; what it shows is that the walk's
+// idle lanes cannot be bought back at this price per iteration.
+#ifndef FR_WCS
+#define FR_WCS 48                     // candidates per chunk of the windowed walk
+#endif
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, FR_V3_WAVES)))
+void k_fisher_tile_v3w(FrParams p, FrFisherArgs f)
+{
+	__shared__ uint32_t s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][2 * FR_WCS][FR_ENT3_F4];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t bx0 = tx * FR_BLOCK_X, by0 = ty * FR_BLOCK_Y + (uint32_t)wave * 4u;
+	const uint32_t pxx = bx0 + (uint32_t)(lane & 15), pxy = by0 + (uint32_t)(lane >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* rec = f.recA + (size_t)v * f.ab_view;
+	const float4* rq = f.recQ + (size_t)v * f.q_view;
+	const size_t rsA = (size_t)f.ab_stride, rsQ = (size_t)f.q_stride;
+	uint32_t* wq = s_q[wave];
+	float4 (*ent)[FR_ENT3_F4] = s_ent[wave];
+	constexpr uint32_t HALF = FR_WCS * FR_ENT3_F4 * 16;          // bytes of one chunk's records
+	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];   // LDS byte address
+	uint32_t ent_lds_v;
+	asm volatile("v_mov_b32 %0, %1" : "=v"(ent_lds_v) : "s"(ent_lds));
+
+	const float strip_lo = (float)by0, strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)bx0, tile_x1 = tile_x0 + 15.0f;
+	float T = 1.0f, Cg = 0.f, Xt = 0.f, sA = 0.f, sB = 0.f, sD = 0.f;
+	bool done = !inside;
+	uint32_t qh = 0, qn = 0;
+#ifdef FR_LOOPSTATS
+	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0;
+#endif
+
+	// key stream, as in k_fisher_tile_v3
+	uint32_t id1 = 0, id2 = 0;
+	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[rsA * id1]; }
+	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
+	uint32_t base = 0;
+	auto stream_fill = [&]() {
+		while (qn < (uint32_t)FR_WCS && base < n)
+		{
+			const uint32_t idc = id1; const float4 rc = r1;
+			id1 = id2;
+			if (base + 64 + lane < n) r1 = rec[rsA * id2];
+			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
+			const uint32_t eb = __float_as_uint(rc.z);
+			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			const bool ov = (base + lane < n) && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi)
+			                && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc;
+			qn += (uint32_t)__popcll(om);
+			base += 64;
+		}
+	};
+	// the next chunk's records, gathered into registers one chunk ahead of their parking
+	float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pq0 = pa, pq1 = pa, pq2 = pa;
+	float pk3 = 0.f;
+	uint32_t pm = 0;
+	auto gather_next = [&]() {
+		pm = qn < (uint32_t)FR_WCS ? qn : (uint32_t)FR_WCS;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if ((uint32_t)lane < pm)
+		{
+			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
+			pa = rec[rsA * id]; pb = rec[rsA * id + 1];
+			pq0 = rq[rsQ * id]; pq1 = rq[rsQ * id + 1]; pq2 = rq[rsQ * id + 2];
+			pk3 = ((const float*)(rq + rsQ * id + 3))[0];
+		}
+		qh = (qh + pm) & (FR_QCAP - 1); qn -= pm;
+	};
+	stream_fill();
+	gather_next();
+
+	unsigned long long cur = 0ull, nxt = 0ull;     // the lane's candidates in the chunk it is walking / in the chunk after it
+	uint32_t cbase = ent_lds_v;                      // LDS byte address of the chunk `cur` refers to
+	uint32_t oldest = 0, resident = 0;               // wave-uniform: half holding the older resident chunk, resident chunks (0..2)
+	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	while (!all_done)
+	{
+		// ---- park the gathered chunk(s) into the free half / halves
+		while (resident < 2u && pm != 0u)
+		{
+			const uint32_t h = (oldest + resident) & 1u;
+			const uint32_t m = pm;
+#ifdef FR_LOOPSTATS
+			dbg_chunks++; dbg_cand += (int)m;
+#endif
+			unsigned long long emask = 0ull;
+			if ((uint32_t)lane < m)
+			{
+				const float4 a = pa, b4 = pb;
+				float4* e = ent[h * FR_WCS + (uint32_t)lane];
+				e[0] = make_float4(a.x, a.y, pk3, a.w);               // k3 in the place of the footprint extents (only needed here)
+				e[1] = b4; e[2] = pq0; e[3] = pq1; e[4] = pq2;
+				emask = fr_footprint_mask<16, 4>(a, b4, strip_lo, tile_x0);
+			}
+			stream_fill();
+			gather_next();
+			unsigned long long mask = fr_wave_transpose64(emask, lane);
+			if (done) mask = 0ull;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (resident == 0u) { cur = mask; cbase = ent_lds_v + h * HALF; }     // nothing was resident: every lane starts on this chunk
+			else nxt = mask;
+			resident++;
+		}
+		if (resident == 0u) break;
+		const uint32_t obase = ent_lds + oldest * HALF;                          // (scalar) the older chunk's records
+		const uint32_t ybase = ent_lds + (oldest ^ 1u) * HALF;                   // the younger chunk's
+		// ---- walk until every lane has left the older chunk.  The votes are kept as 64-bit scalar masks (v_cmp writes them, s_and /
+		// s_andn2 combine them): `older` = the lanes still on the older chunk (all of them at the start of a round).
+		unsigned long long older = ~0ull;
+		while (true)
+		{
+			const unsigned long long c0 = __builtin_amdgcn_uicmpl(cur, 0ull, 32 /* eq */);
+			const unsigned long long nn = __builtin_amdgcn_uicmpl(nxt, 0ull, 33 /* ne */);
+			// a lane that has finished the older chunk moves on to the younger one (nxt != 0 only while the lane is on the older chunk)
+			const unsigned long long swm = c0 & nn;
+			if (swm != 0ull)
+			{
+				if (__builtin_amdgcn_inverse_ballot_w64(swm)) { cur = nxt; nxt = 0ull; cbase = ybase; }
+				older &= ~swm;
+			}
+			const unsigned long long livem = ~c0 | swm;
+			if ((livem & older) == 0ull) break;
+#ifdef FR_LOOPSTATS
+			dbg_wsteps++;
+#endif
+			if (__builtin_amdgcn_inverse_ballot_w64(livem))
+			{
+				const int j = __builtin_ctzll(cur);                  // (cur != 0 on every live lane)
+				cur &= cur - 1ull;
+				FrWalkRec3 r;
+				{
+					const uint32_t addr = cbase + (uint32_t)j * (FR_ENT3_F4 * 16);
+					asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+					             "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\t"
+					             "s_waitcnt lgkmcnt(0)"
+					             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2) : "v"(addr) : "memory");
+				}
+#ifdef FR_LOOPSTATS
+				dbg_steps++;
+#endif
+				const FrWalkGeom g = fr_walk_geom(r, pfx, pfy);
+				const bool kill = fr_walk_update(g, g.ok, T, Cg, Xt, sA, sB, sD);
+#ifdef FR_LOOPSTATS
+				dbg_hits += (g.ok && !kill) ? 1 : 0;
+#endif
+				if (kill) { cur = 0ull; nxt = 0ull; done = true; }
+			}
+		}
+		// ---- the older chunk is finished by every lane: its half is free, the younger chunk becomes the older one
+		cbase = ybase;                                   // (lanes that had not moved on hold cur == 0 and nxt == 0 here)
+		oldest ^= 1u; resident--;
+		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	}
+	const float X = Cg + T * (p.bg[0] + p.bg[1] + p.bg[2]);
+	const float dlt = X - Xt;
+	float score = inside ? (sA + dlt * (dlt * sD - 2.0f * sB)) : 0.f;
+	float ws = wave_sum(score);
+#ifdef FR_LOOPSTATS
+	if (f.debug_mode >= 2)
+		ws = f.debug_mode == 2 ? (float)dbg_cand : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_wsteps
+		   : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : f.debug_mode == 7 ? (float)wave_max_i(dbg_steps) : wave_sum((float)dbg_steps);
+	else
+#endif
+	ws *= f.dL * f.dL;
+	// the four partial sums through the (now idle) queue memory: s_q[w][0] belongs to wave w alone until the barrier
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) wq[0] = __float_as_uint(ws);
+	__syncthreads();
+	if (tid == 0) f.tile_scores[vt] = (__uint_as_float(s_q[0][0]) + __uint_as_float(s_q[1][0])) + (__uint_as_float(s_q[2][0]) + __uint_as_float(s_q[3][0]));
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Forward compositing with the scorer's walk (k_fisher_tile_v3): the wave streams the tile's keys, keeps the splats whose
 // alpha footprint box meets its strip in an LDS ring, and then takes 64 candidates at a time -- one per lane: the lane parks
 // the candidate's record in LDS and rasterises its footprint ellipse into a 64-bit mask over the strip's pixels; a 64 x 64 bit
@@ -5307,8 +5505,10 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
 		(void)hipEventRecord(ev0, s);
 	}
-	// FR_DEBUG_MODE=8: 8 x 8 pixel blocks per wave instead of 16 x 4 strips (A/B runs; measured 5 % slower on MI355X)
+	// FR_DEBUG_MODE=8: 8 x 8 pixel blocks per wave instead of 16 x 4 strips (A/B runs; measured 5 % slower on MI355X);
+	// FR_DEBUG_MODE=24: the rolling two-chunk window (k_fisher_tile_v3w: 24 % fewer walk iterations, 8 % slower -- see there)
 	if (f.debug_mode == 8) hipLaunchKernelGGL((k_fisher_tile_v3<8, 8>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	else if (f.debug_mode == 24) hipLaunchKernelGGL(k_fisher_tile_v3w, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f);
 	else hipLaunchKernelGGL((k_fisher_tile_v3<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	if (g_prof_on)
 	{
