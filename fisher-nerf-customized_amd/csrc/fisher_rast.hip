@@ -2810,6 +2810,13 @@ __device__ __forceinline__ bool fr_walk_update(const FrWalkGeom& g, bool live, f
 	return kill;
 }
 
+// FR_LDK: the tile kernel's key loads (-DFR_NT_KEYS: non-temporal, to keep the keys out of the L2 the record gathers live in:
+// measured 1-4 % slower, tools/ab.sh)
+#ifdef FR_NT_KEYS
+#define FR_LDK(p) __builtin_nontemporal_load(p)
+#else
+#define FR_LDK(p) (*(p))
+#endif
 #define FR_QCAP 128                  // per-wave candidate queue (ring of Gaussian indices): at most 63 left over + 64 new
 // One workgroup per (tile, view); the four waves own the four 16x4 strips and never synchronise until the final sum.
 //  stream   a wave reads the tile's sorted keys 64 at a time (one per lane), gathers recA and keeps the splats whose
@@ -2871,8 +2878,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	// software pipeline of the key stream: id1 / r1 = indices and recA of the chunk at `base`, id2 = indices of the next one
 	uint32_t id1 = 0, id2 = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[rsA * id1]; }
-	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
+	if ((uint32_t)lane < n) { id1 = (uint32_t)FR_LDK(gk + lane); r1 = rec[rsA * id1]; }
+	if (64u + lane < n) id2 = (uint32_t)FR_LDK(gk + 64 + lane);
 	uint32_t base = 0;
 	// ---- stream: fill the queue up to one chunk
 	auto stream_fill = [&]() {
@@ -2884,7 +2891,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 			const uint32_t idc = id1; const float4 rc = r1;
 			id1 = id2;
 			if (base + 64 + lane < n) r1 = rec[rsA * id2];
-			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
+			if (base + 128 + lane < n) id2 = (uint32_t)FR_LDK(gk + base + 128 + lane);
 			const uint32_t eb = __float_as_uint(rc.z);
 			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
 			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
@@ -3254,7 +3261,6 @@ void k_fisher_tile_v3w(FrParams p, FrFisherArgs f)
 			resident++;
 		}
 		if (resident == 0u) break;
-		const uint32_t obase = ent_lds + oldest * HALF;                          // (scalar) the older chunk's records
 		const uint32_t ybase = ent_lds + (oldest ^ 1u) * HALF;                   // the younger chunk's
 		// ---- walk until every lane has left the older chunk.  The votes are kept as 64-bit scalar masks (v_cmp writes them, s_and /
 		// s_andn2 combine them): `older` = the lanes still on the older chunk (all of them at the start of a round).
