@@ -3035,7 +3035,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	{
 		// 2: candidates, 3: chunks, 4: wave-level walk iterations, 5: contributing pairs, 6: lane-level walk steps, 7: steps of the busiest lane
 		// 10 / 11 / 12: the wave's s_memtime ticks (/ 64) in the key stream / the chunk set-up / the walk
-		if (f.debug_mode >= 10) ws = (float)((f.debug_mode == 10 ? dbg_ts : f.debug_mode == 11 ? dbg_tc : dbg_tw) >> 6);
+		if (f.debug_mode == 13) ws = (float)(base < n ? base : n);            // keys this wave streamed before its 64 pixels were finished
+		else if (f.debug_mode == 14) ws = (float)n;                           // ... of the tile's n (both summed over the four waves)
+		else if (f.debug_mode >= 10) ws = (float)((f.debug_mode == 10 ? dbg_ts : f.debug_mode == 11 ? dbg_tc : dbg_tw) >> 6);
 		else
 		ws = f.debug_mode == 2 ? (float)dbg_cand : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_wsteps
 		   : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : f.debug_mode == 7 ? (float)wave_max_i(dbg_steps) : wave_sum((float)dbg_steps);
