@@ -111,8 +111,16 @@ struct FrParams {
 	struct FrVisEntry* vis_list; // [V][blocks][FR_THREADS * G] compacted visible splats of each preprocess workgroup
 	uint32_t* vis_n;             // [V][blocks] their number
 	int VC;                      // views per preprocess workgroup
+	uint32_t tile_cap;           // 0: tile segments packed by the scan; > 0: every (view, tile) owns keys[(v T + t) tile_cap ...), filled by
+	                             // the projection kernel itself (k_preprocess_views_c<.., true>): no scan dependency, no scatter kernel
 	int legacy_sort;             // FR_DEBUG_MODE=6: the LDS-resident sort network of round 1 (A/B runs)
+	int ablate;                  // -DFR_ABLATE builds only (tools/fe_ablate.py): FR_DEBUG_MODE 30..34 drop parts of the direct key scatter
 };
+#ifdef FR_ABLATE
+#define FR_ABL(x) x
+#else
+#define FR_ABL(x)
+#endif
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -395,6 +403,40 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 			uint32_t b = (v + 1 < V) ? off[(size_t)(v + 1) * T] : carry;
 			num_rendered[v] = (int)(b - a);
 		}
+	}
+}
+
+// Fixed key segments (FrParams::tile_cap): nothing to scan.  off[i] = i tile_cap, the list of long tiles, and the status word
+// {total, a tile over its capacity, longest list, the same flag} by atomics on the zero-filled words; four tiles per thread.
+__global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int N, uint32_t tile_cap,
+                                                           int* __restrict__ status, uint32_t* __restrict__ big_list, int ablate)
+{
+	const int i0 = (blockIdx.x * FR_THREADS + threadIdx.x) * 4;
+	uint32_t sum = 0, mx = 0;
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+	{
+		const int i = i0 + q;
+		if (i >= N) break;
+		const uint32_t c = cnt[i];
+		off[i] = (uint32_t)i * tile_cap;
+		sum += c;
+		mx = c > mx ? c : mx;
+		if (c > (uint32_t)FR_SORT_SMALL_KEYS) big_list[16 + atomicAdd(&big_list[0], 1u)] = (uint32_t)i;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+		const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64);
+		mx = t > mx ? t : mx;
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		if (sum) atomicAdd(&status[0], (int)sum);
+		if (mx) atomicMax(&status[2], (int)mx);
+		if (mx > tile_cap) { atomicOr(&status[1], 1); atomicOr(&status[3], 1); }
+		FR_ABL(if (ablate >= 30) atomicOr(&status[1], 1);)
 	}
 }
 
@@ -790,12 +832,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 //       (fr_fisher_record_one), and writes the 96-byte record to its slot and the 16-byte list entry beside it -- consecutive
 //       threads, consecutive records.
 // No bitmaps, no prefix popcounts, no second pass over the lists.  Records, lists and counts are identical to the other form's.
-template <int C, int AF>
+// DK (direct keys, FrParams::tile_cap > 0): every (view, tile) owns a fixed segment of the key buffer, so a workgroup needs no
+// scan of the tile counts to place its keys: once its histogram is complete it claims its ranges (the same one atomic per
+// non-empty (view, tile) that the other form uses for blk_base) and scatters the keys of its own visible lists right away,
+// underneath the projection arithmetic of the other workgroups on the CU -- k_scatter_vis (latency-bound, 0.15 ms of the
+// 64-view step on its own) and the blk_base array disappear, k_scan_tiles only builds the lists of long tiles.  The order of the
+// keys inside a segment is arbitrary either way; the sort makes it the reference's.
+template <int C, int AF, bool DK>
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, FrRecordArgs ra)
 {
 	static_assert((C == 4 || C == 11) && AF >= 0 && AF <= 2 && !(AF == 1 && C != 4), "records modes: score form, A-form (4 columns), general out_H form");
 	constexpr int RS = FrRecStride<C, AF>::value;     // float4 per compact record
-	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12] | park[13][FR_THREADS]
+	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12] | park[13][FR_THREADS] | DK: cursor[VC][T]
 	const int VC = p.VC;
 	uint32_t* hist = fr_dyn_lds;
 	uint32_t* pairs = hist + (size_t)VC * p.T;
@@ -857,13 +905,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				bool keep = live && !(p_view.z <= 0.001f);
 				if (early)
 				{
+					// (a bound, not the projection: v_rcp_f32 / v_sqrt_f32 are a few 1e-7 off, the slack below is 1e-3 and two pixels)
 					const fr_f4 ph = fr_xform4x4(po, pm);
-					const float p_w = 1.0f / (ph.w + 0.0000001f);
+					const float p_w = __builtin_amdgcn_rcpf(ph.w + 0.0000001f);
 					const float px = ((ph.x * p_w + 1.0f) * (float)p.W - 1.0f) * 0.5f, py = ((ph.y * p_w + 1.0f) * (float)p.H - 1.0f) * 0.5f;
-					const float iz = 1.0f / p_view.z;
+					const float iz = __builtin_amdgcn_rcpf(p_view.z);
 					const float jx = fminf(fabsf(p_view.x * iz) * 1.001f, lx), jy = fminf(fabsf(p_view.y * iz) * 1.001f, ly);
 					const float kc = fx2 * (1.0f + jx * jx) + fy2 * (1.0f + jy * jy);
-					const float rb = 3.0f * sqrtf(kc * tr * (iz * iz) + 0.7f) + 2.0f;
+					const float rb = 3.0f * __builtin_amdgcn_sqrtf(kc * tr * (iz * iz) + 0.7f) * 1.000001f + 2.0f;
 					const bool outside = (px + rb < 0.f) || (px - rb > xmax) || (py + rb < 0.f) || (py - rb > ymax);
 					keep = keep && !outside;
 				}
@@ -892,6 +941,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			}
 		}
 		__syncthreads();
+		FR_ABL(if (p.ablate == 35) np = 0;)                      // 35: phase A only
 		for (uint32_t e0 = 0; e0 < np; e0 += FR_THREADS)
 		{
 			const uint32_t e = e0 + (uint32_t)tid;
@@ -989,6 +1039,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			}
 			__syncthreads();
 			// ---- phase C: the r-th visible pair of the batch
+			FR_ABL(if (p.ablate == 36) nvis = 0;)                   // 36: no phase C (no records, no list entries)
 			if ((uint32_t)tid < nvis)
 			{
 					const int r = tid;
@@ -1006,26 +1057,135 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 #pragma unroll
 				for (int k = 0; k < 12; k++) wm[k] = has_w2c ? s_wm[12 * cvv + k] : 0.f;
 				float4* rec_out = ra.comp + ((size_t)v * PV + slot) * RS;
+				FR_ABL(if (p.ablate == 37) rec_out = ra.comp + (size_t)tid * RS;)     // 37: the records' arithmetic without their HBM traffic
 				if constexpr (AF == 2) fr_fisher_record_general<C>(p, ra.packed, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
 				else fr_fisher_record_one<C, false, (AF == 1)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
-				FrVisEntry en;
-				en.idx = slot; en.depth_bits = park[9 * FR_THREADS + r];          // the keys carry the slot
-				en.xy0 = park[10 * FR_THREADS + r]; en.xy1 = park[11 * FR_THREADS + r];
-				*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)) = *(const uint4*)&en;
+				if constexpr (DK)
+				{
+					// 8-byte list entry {depth, x0 | y0 << 8 | width << 16 | height << 24} (tile grids up to 255 x 255: fr_fisher_views);
+					// the slot is the entry's place in the list
+					const uint32_t xy0 = park[10 * FR_THREADS + r], xy1 = park[11 * FR_THREADS + r];
+					const uint32_t rect = (xy0 & 255u) | ((xy0 >> 16) << 8) | (((xy1 & 0xffffu) - (xy0 & 0xffffu)) << 16) | (((xy1 >> 16) - (xy0 >> 16)) << 24);
+					((uint2*)p.vis_list)[((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)] = make_uint2(park[9 * FR_THREADS + r], rect);
+				}
+				else
+				{
+					FrVisEntry en;
+					en.idx = slot; en.depth_bits = park[9 * FR_THREADS + r];          // the keys carry the slot
+					en.xy0 = park[10 * FR_THREADS + r]; en.xy1 = park[11 * FR_THREADS + r];
+					*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)) = *(const uint4*)&en;
+				}
 				if constexpr (AF != 0) ra.slot_idx[(size_t)v * PV + slot] = idx;    // (the out_H kernels go back to the index)
 			}
 			__syncthreads();                                        // park[], s_wtot and s_bv are reused by the next batch
 		}
 	}
-	for (int vv = 0; vv < nv; vv++)
+	if constexpr (DK)
 	{
-		const int v = v0 + vv;
-		uint32_t* cnt = p.tile_cnt + (size_t)v * p.T;
-		const uint32_t* h = hist + (size_t)vv * p.T;
-		for (int t = tid; t < p.T; t += FR_THREADS)
+		uint32_t* cursor = park + 13 * FR_THREADS;
+		// (the barrier that ended the last batch: every histogram add and every list entry of this workgroup is done and visible)
+		// The workgroup's visible lists, all its views laid end to end, are swept NB x 256 entries at a time; the first round's
+		// loads are issued before the range claims, every later round's before the round in hand is scattered.
+		uint32_t vend[FR_VC_MAX];
+		uint32_t ntot = 0;
+#pragma unroll
+		for (int k = 0; k < FR_VC_MAX; k++) { if (k < nv) ntot += s_n[k]; vend[k] = ntot; }
+		FR_ABL(if (p.ablate == 31) ntot = 0;)
+		constexpr int NB = 4;
+		uint2 en[NB], nx[NB];
+		uint32_t ev[NB], nxv[NB];
+		auto load_round = [&](uint32_t e0, uint2 (&de)[NB], uint32_t (&dv)[NB])
 		{
-			const uint32_t c = h[t];
-			if (c) p.blk_base[((size_t)v * nblk + blockIdx.x) * p.T + t] = atomicAdd(&cnt[t], c);
+#pragma unroll
+			for (int b = 0; b < NB; b++)
+			{
+				const uint32_t e = e0 + b * FR_THREADS + tid;
+				uint32_t vv = 0, lo = 0;
+#pragma unroll
+				for (int k = 0; k < FR_VC_MAX - 1; k++) if (e >= vend[k]) { vv = k + 1; lo = vend[k]; }
+				dv[b] = vv;
+				de[b] = make_uint2(0u, 0u);                                  // empty rect
+				FR_ABL(if (p.ablate == 33) { if (e < ntot) de[b] = make_uint2(e, (e & 7u) | ((e >> 3 & 15u) << 8) | (2u << 16) | (1u << 24)); } else)
+				if (e < ntot) de[b] = ((const uint2*)p.vis_list)[((size_t)(v0 + vv) * nblk + blockIdx.x) * cap + (e - lo)];
+			}
+		};
+		load_round(0u, en, ev);
+		// claims: four bins per thread and trip, their atomics in flight together
+		const int nb = nv * p.T;
+		for (int b0 = 0; b0 < nb; b0 += 4 * FR_THREADS)
+		{
+			uint32_t c[4], at[4], gt[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const int b = b0 + k * FR_THREADS + tid;
+				c[k] = b < nb ? hist[b] : 0u;
+				gt[k] = (uint32_t)(v0 + b / p.T) * (uint32_t)p.T + (uint32_t)(b % p.T);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				at[k] = 0u;
+				FR_ABL(if (p.ablate != 34))
+				if (c[k]) at[k] = atomicAdd(&p.tile_cnt[gt[k]], c[k]);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const int b = b0 + k * FR_THREADS + tid;
+				if (b < nb)
+				{
+					// over capacity: no key of this range is written -- k_tile_lists raises the flag from the count
+					hist[b] = (c[k] && at[k] + c[k] <= p.tile_cap) ? gt[k] * p.tile_cap + at[k] : 0xffffffffu;
+					cursor[b] = 0u;
+				}
+			}
+		}
+		__syncthreads();
+		for (uint32_t e0 = 0; e0 < ntot; e0 += NB * FR_THREADS)
+		{
+			const bool more = e0 + NB * FR_THREADS < ntot;
+			if (more) load_round(e0 + NB * FR_THREADS, nx, nxv);
+#pragma unroll
+			for (int b = 0; b < NB; b++)
+			{
+				// the slot is the entry's place in its list: the keys carry it (monotone in the Gaussian index)
+				const uint32_t e = e0 + b * FR_THREADS + tid;
+				const uint32_t lo = ev[b] ? vend[ev[b] - 1] : 0u;
+				const uint64_t key = ((uint64_t)en[b].x << 32) | (blockIdx.x * cap + (e - lo));
+				const uint32_t r = en[b].y;
+				const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = x0 + ((r >> 16) & 255u), y1 = y0 + (r >> 24);
+				const uint32_t* hb = hist + (size_t)ev[b] * p.T;
+				uint32_t* cu = cursor + (size_t)ev[b] * p.T;
+				for (uint32_t y = y0; y < y1; y++)
+					for (uint32_t x = x0; x < x1; x++)
+					{
+						const uint32_t t = y * p.gx + x;
+						const uint32_t base = hb[t];
+						const uint32_t k = atomicAdd(&cu[t], 1u);
+						FR_ABL(if (p.ablate != 32 && p.ablate != 33))
+						if (base != 0xffffffffu) p.keys[base + k] = key;
+					}
+			}
+			if (more)
+			{
+#pragma unroll
+				for (int b = 0; b < NB; b++) { en[b] = nx[b]; ev[b] = nxv[b]; }
+			}
+		}
+	}
+	else
+	{
+		for (int vv = 0; vv < nv; vv++)
+		{
+			const int v = v0 + vv;
+			uint32_t* cnt = p.tile_cnt + (size_t)v * p.T;
+			const uint32_t* h = hist + (size_t)vv * p.T;
+			for (int t = tid; t < p.T; t += FR_THREADS)
+			{
+				const uint32_t c = h[t];
+				if (c) p.blk_base[((size_t)v * nblk + blockIdx.x) * p.T + t] = atomicAdd(&cnt[t], c);
+			}
 		}
 	}
 	if (tid < nv)
@@ -3804,11 +3964,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __res
                                                               const int* __restrict__ status, int n_groups, float* __restrict__ out_scores,
                                                               int* __restrict__ status_out)
 {
-	// status: one {total, overflow, max tile count, 0} per view group of the call; the caller's copy is {sum, any, max, 0}, and an
+	// status: one {total, overflow, max tile count, tile over its fixed capacity} per view group of the call; the caller's copy is
+	// {sum, any, max, any}, and an
 	// overflow of ANY group leaves every score unwritten (the caller grows the buffer and repeats the call)
-	int tot = 0, ovf = 0, mx = 0;
-	for (int g = 0; g < n_groups; g++) { tot += status[4 * g]; ovf |= status[4 * g + 1]; mx = status[4 * g + 2] > mx ? status[4 * g + 2] : mx; }
-	if (blockIdx.x == 0 && threadIdx.x == 0) { status_out[0] = tot; status_out[1] = ovf; status_out[2] = mx; status_out[3] = 0; }
+	int tot = 0, ovf = 0, mx = 0, tov = 0;
+	for (int g = 0; g < n_groups; g++) { tot += status[4 * g]; ovf |= status[4 * g + 1]; mx = status[4 * g + 2] > mx ? status[4 * g + 2] : mx; tov |= status[4 * g + 3]; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) { status_out[0] = tot; status_out[1] = ovf; status_out[2] = mx; status_out[3] = tov; }
 	if (ovf || !out_scores) return;
 	__shared__ double s_part[FR_THREADS];
 	const int v = blockIdx.x, tid = threadIdx.x;
@@ -4950,6 +5111,7 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 	p.scales = g->scales; p.rots = g->rotations;
 	p.VC = 1;
 	p.legacy_sort = fr_debug_mode() == 6;
+	FR_ABL(p.ablate = fr_debug_mode();)
 }
 
 // Launches cov3d, preprocess, scan, scatter, sort for V views.  p must carry the carved buffers.
@@ -5078,12 +5240,19 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
 		// compact records: written once, in place, by k_preprocess_views_c (FR_DEBUG_MODE=20 keeps the parking form for A/B runs)
 		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
-		const size_t lds_c = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
-		if (once && plan->general && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 2>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
-		else if (once && plan->general) hipLaunchKernelGGL((k_preprocess_views_c<11, 2>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
-		else if (once && plan->form_a) hipLaunchKernelGGL((k_preprocess_views_c<4, 1>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
-		else if (once && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 0>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
-		else if (once) hipLaunchKernelGGL((k_preprocess_views_c<11, 0>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		if (!once) p.tile_cap = 0;                       // fixed key segments are filled by k_preprocess_views_c only
+		const bool dk = p.tile_cap != 0;
+		const size_t lds_c = ((size_t)p.VC * p.T * (dk ? 2 : 1) + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
+		if (once && plan->general && plan->columns == 4 && dk) hipLaunchKernelGGL((k_preprocess_views_c<4, 2, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->general && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 2, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->general && dk) hipLaunchKernelGGL((k_preprocess_views_c<11, 2, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->general) hipLaunchKernelGGL((k_preprocess_views_c<11, 2, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->form_a && dk) hipLaunchKernelGGL((k_preprocess_views_c<4, 1, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->form_a) hipLaunchKernelGGL((k_preprocess_views_c<4, 1, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->columns == 4 && dk) hipLaunchKernelGGL((k_preprocess_views_c<4, 0, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 0, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once && dk) hipLaunchKernelGGL((k_preprocess_views_c<11, 0, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
+		else if (once) hipLaunchKernelGGL((k_preprocess_views_c<11, 0, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->form_a) hipLaunchKernelGGL((k_preprocess_views<-4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
@@ -5092,13 +5261,19 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	}
 	else
 	{
+		p.tile_cap = 0;
 		hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
 		if ((rc = fr_check_launch("k_preprocess"))) return rc;
 	}
+	if (multi && p.tile_cap)
+		hipLaunchKernelGGL(k_tile_lists, dim3((p.V * p.T + 4 * FR_THREADS - 1) / (4 * FR_THREADS)), dim3(FR_THREADS), 0, s, p.tile_cnt, p.tile_off, p.V * p.T,
+		                   p.tile_cap, p.status, p.big_list, p.ablate);
+	else
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
 	                   p.key_capacity, p.status, multi ? (int*)nullptr : p.num_rendered, p.big_list);
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
-	if (multi) hipLaunchKernelGGL(k_scatter_vis, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
+	if (multi && p.tile_cap) { /* the projection kernel has placed the keys */ }
+	else if (multi) hipLaunchKernelGGL(k_scatter_vis, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	else hipLaunchKernelGGL(k_scatter_keys, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
 	if ((rc = fr_check_launch("k_scatter_keys"))) return rc;
 	// Single-view front end in a records mode: k_fisher_records turns the FrSplat records into the scorer's form IN PLACE, so it
@@ -5124,6 +5299,8 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	if (forked) joins.forked(&side);
 	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
+	// (the middle tier on a side stream of its own as well, all three tiers at once: 2.04 ms per 64-view step against 1.95 --
+	// the 256-thread tiers take each other's LDS and wave slots)
 	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
 	const int mid_blocks = p.T * p.V < 2048 ? p.T * p.V : 2048;
@@ -5637,6 +5814,14 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	p.blk_base = (uint32_t*)(ws + L.blk_base);
 	p.keys = (uint64_t*)(ws + L.keys);
 	p.key_capacity = max_rendered;
+	if (fc->tile_capacity < 0) return fr_fail(FR_EINVAL, "fr_fisher_views: negative tile_capacity");
+	if (fc->tile_capacity > 0)
+	{
+		// fixed key segments: V T tile_capacity keys must fit the key buffer (and 32-bit offsets)
+		const long long need = (long long)V * p.T * (long long)fc->tile_capacity;
+		if (need > max_rendered || need >= (1ll << 32)) return fr_fail(FR_EINVAL, "fr_fisher_views: n_views * tiles * tile_capacity exceeds max_rendered (or 2^32)");
+		if (p.gx <= 255u && p.gy <= 255u) p.tile_cap = (uint32_t)fc->tile_capacity;      // (the 8-byte list entries hold tile coordinates in bytes; else: packed lists)
+	}
 	p.vis_count = fc->out_vis_count;
 	p.num_rendered = fc->out_num_rendered;
 	FrFisherArgs f;
@@ -5721,6 +5906,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		pg.status = p.status + 4 * gi;
 		pg.big_list = p.big_list + (size_t)v0 * p.T + 16 * gi;
 		pg.blk_base = p.blk_base + (size_t)v0 * (size_t)fr_preprocess_blocks(P, V) * (size_t)p.T;
+		pg.tile_cap = p.tile_cap;                                  // (fr_bin_pipeline clears it where the front end cannot fill fixed segments)
 		const long long k0 = (long long)((__int128)max_rendered * v0 / V), k1 = (long long)((__int128)max_rendered * (v0 + Vg) / V);
 		pg.keys = p.keys + k0; pg.key_capacity = k1 - k0;
 		pg.vis_count = p.vis_count ? p.vis_count + v0 : nullptr;

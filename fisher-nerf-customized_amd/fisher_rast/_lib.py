@@ -60,6 +60,7 @@ class FisherCfg(ctypes.Structure):
         ("out_num_rendered", ctypes.c_void_p),
         ("dL_dpix_image", _f32p),
         ("dL_image_view_stride", ctypes.c_int64),
+        ("tile_capacity", ctypes.c_int32),
     ]
 
 

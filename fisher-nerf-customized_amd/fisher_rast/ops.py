@@ -242,6 +242,7 @@ class FisherScorer:
     """
 
     WORKSPACE_BUDGET = 32 << 30  # bytes of workspace (of the MI355X's 288 GB) before views are processed in chunks: ~580 views at 500k Gaussians
+    MAX_KEY_BYTES_PER_VIEW = 512 << 20  # fixed key segments beyond this per view: packed lists instead (tile_capacity = 0)
 
     def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
                  dL_dpix: float = 1e-3):
@@ -272,6 +273,14 @@ class FisherScorer:
         # one launch, 4 groups 2.76 ms (the staggered form inside fr_fisher_views, FR_GROUPS: 2.32 / 2.56) -- one group is the default
         self.n_streams = max(1, int(os.environ.get("FR_STREAMS", "1")))
         self.per_view_capacity = max(int(0.75 * self.P), 1 << 16)
+        # Fixed key segments (fr_fisher_cfg.tile_capacity): every (view, tile) owns `tile_capacity` key slots, the projection
+        # kernel places the keys itself and the scan / scatter kernels drop out of the launch sequence.  16384 keys (the largest
+        # list the in-LDS sort tiers take) x 8 B = 128 KiB per tile -- 32 MiB per 256 x 256 view of the 288 GB; a longer list
+        # raises the overflow flag and `run` grows the segments, or goes back to packed lists where they would not fit.
+        self.tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        self.tile_capacity = int(os.environ.get("FR_TILE_CAPACITY", "16384"))
+        if self.tiles * self.tile_capacity * 8 > self.MAX_KEY_BYTES_PER_VIEW:
+            self.tile_capacity = 0
         self.cfg = _raster_cfg(self.P, self.H, self.W, raster_settings.tanfovx, raster_settings.tanfovy,
                                raster_settings.scale_modifier, raster_settings.sh_degree, 0,
                                raster_settings.prefiltered, self.bg, self.view, self.proj, self.campos)
@@ -281,10 +290,13 @@ class FisherScorer:
     def max_views_per_launch(self):
         """Views per fr_fisher_views call that keep the workspace within WORKSPACE_BUDGET (the per-view share is what the
         library itself reports: records, visible lists, keys, per-tile arrays)."""
-        one = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 1, self.per_view_capacity, self.columns))
-        eight = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 8, 8 * self.per_view_capacity, self.columns))
+        one = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 1, self._keys_per_view(), self.columns))
+        eight = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 8, 8 * self._keys_per_view(), self.columns))
         per_view = max(1, (eight - one) // 7)
         return max(1, int(self.WORKSPACE_BUDGET // per_view))
+
+    def _keys_per_view(self):
+        return max(self.per_view_capacity, self.tiles * self.tile_capacity)
 
     def _workspace(self, V, max_rendered, slot=0):
         nbytes = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, V, max_rendered, self.columns))
@@ -343,10 +355,11 @@ class FisherScorer:
                 if gi > 0:
                     stream.wait_stream(cur)
                 Vg = v1 - v0
-                max_rendered = Vg * self.per_view_capacity
+                max_rendered = Vg * self._keys_per_view()
                 ws = self._workspace(Vg, max_rendered, gi)
                 fc = FisherCfg()
                 fc.n_views, fc.columns, fc.dL_dpix = Vg, C, self.dL
+                fc.tile_capacity = self.tile_capacity if Vg * self.tiles * self.tile_capacity < (1 << 32) else 0
                 fc.w2c = ctypes.c_void_p(w2c.data_ptr() + v0 * 64)
                 if H_inv is not None:
                     fc.H_inv = ctypes.c_void_p(H_inv.data_ptr() + (v0 * PC * 4 if H_inv_per_view else 0))
@@ -398,7 +411,11 @@ class FisherScorer:
                     break
                 # tile-instance buffer too small: NOTHING was scored or accumulated (every kernel behind the scan returns on the
                 # overflow flag, include/fisher_rast.h), so out_H is as it was: grow and redo this chunk
-                self.per_view_capacity = int(int(st[0]) * 1.25 / (v1 - v0)) + 4096
+                if int(st[3]):
+                    # a tile list longer than its fixed segment (st[2] = the longest): longer segments, or packed lists
+                    want = (int(int(st[2]) * 1.25) + 1023) // 1024 * 1024
+                    self.tile_capacity = want if self.tiles * want * 8 <= self.MAX_KEY_BYTES_PER_VIEW else 0
+                self.per_view_capacity = max(self.per_view_capacity, int(int(st[0]) * 1.25 / (v1 - v0)) + 4096)
                 chunk = min(chunk, self.max_views_per_launch())
                 if v1 - v0 > chunk:
                     v1 = v0 + chunk

@@ -174,6 +174,10 @@ typedef struct fr_fisher_cfg {
 	                               dL_dpix -- the `im.backward(gradient=z)` probes of estimate_diag_JtJ_simple /
 	                               estimate_block_JtJ (gaussian_object.py:2088-2098, 2158-2170).  out_H mode only. */
 	int64_t dL_image_view_stride; /* elements between views' images (0 = one image shared by all views) */
+	int32_t tile_capacity;      /* 0: the keys of all (view, tile) lists are packed into max_rendered slots (count, scan, scatter).
+	                               > 0: every (view, tile) owns a fixed segment of tile_capacity keys, which the projection kernel
+	                               fills itself -- no scan dependency and no scatter kernel; needs n_views * tiles * tile_capacity
+	                               <= max_rendered (and < 2^32).  A tile with more instances than that: overflow, status[3] = 1. */
 } fr_fisher_cfg;
 
 size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);
@@ -187,8 +191,8 @@ int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32_t n_views,
 /* Scores n_views candidate poses in one batched launch sequence.  g->means3D are WORLD positions; each view's
  * camera-frame means are computed in-kernel from cfg_f->w2c and then rendered through cfg->viewmatrix/projmatrix
  * exactly as the reference does (gaussian.py:1523-1548; its camera has viewmatrix = I).
- * status (device int32[4]) receives {total tile instances, overflow}; on overflow (total > max_rendered) no
- * score is written. */
+ * status (device int32[4]) receives {total tile instances, overflow, largest tile list, tile_capacity exceeded}; on overflow
+ * (total > max_rendered, or a tile list longer than cfg_f->tile_capacity) no score is written and nothing is accumulated. */
 int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, const fr_fisher_cfg* cfg_f,
                     void* workspace, size_t workspace_bytes, int64_t max_rendered,
                     int32_t* status, fr_stream_t stream);

@@ -1,0 +1,98 @@
+"""-m gpu: the two key layouts of fr_fisher_views -- packed lists (count, scan, scatter kernel; fr_fisher_cfg.tile_capacity = 0)
+and fixed per-(view, tile) segments filled by the projection kernel itself (tile_capacity > 0, the scorer's default).  The sorted
+lists are the same lists, so scores are bit-identical; a list longer than its segment raises the overflow flag, nothing is
+scored or accumulated, and FisherScorer.run grows the segments (or goes back to packed lists) and repeats the launch."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from scenes import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(gpu):
+    from fisher_rast import synthetic
+    from models.SLAM.utils.recon_helpers import setup_camera
+    P, V, W, H = 60_000, 16, 256, 256
+    act = synthetic.activate(synthetic.room_shell(P, seed=7))
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(V, seed=7)).to(gpu)
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    H_inv = (torch.rand((P, 11), generator=torch.Generator().manual_seed(5)) + 0.05).to(gpu)
+    return dict(P=P, V=V, W=W, H=H, act=act, w2c=w2c, cam=cam, H_inv=H_inv)
+
+
+def _scorer(s, gpu, columns, tile_capacity):
+    from fisher_rast.ops import FisherScorer
+    sc = FisherScorer(s["cam"], *(s["act"][k].to(gpu) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")), columns=columns)
+    sc.tile_capacity = tile_capacity
+    return sc
+
+
+@pytest.mark.parametrize("columns", [4, 11])
+def test_fixed_segments_equal_packed_lists(scene, gpu, columns):
+    s = scene
+    hinv = s["H_inv"][:, :columns].contiguous()
+    packed = _scorer(s, gpu, columns, 0)
+    fixed = _scorer(s, gpu, columns, 16384)
+    a = packed.run(s["w2c"], H_inv=hinv)
+    b = fixed.run(s["w2c"], H_inv=hinv)
+    assert packed.tile_capacity == 0 and fixed.tile_capacity == 16384          # no overflow, no change of layout
+    assert torch.equal(a["scores"], b["scores"]) and float(a["scores"].min()) > 0
+    assert torch.equal(a["vis_count"], b["vis_count"]) and torch.equal(a["num_rendered"], b["num_rendered"])
+    # the accumulating modes (float atomics: equal up to the order of the adds)
+    Ha = torch.zeros((s["P"], columns), device=gpu)
+    Hb = torch.zeros((s["P"], columns), device=gpu)
+    packed.run(s["w2c"], out_H=Ha)
+    fixed.run(s["w2c"], out_H=Hb)
+    assert rel_err(Hb.cpu().numpy(), Ha.cpu().numpy()) < 1e-5 and float(Ha.max()) > 0
+
+
+def test_a_list_longer_than_its_segment_grows_the_segments(scene, gpu):
+    s = scene
+    hinv = s["H_inv"][:, :4].contiguous()
+    packed = _scorer(s, gpu, 4, 0)
+    want = packed.run(s["w2c"], H_inv=hinv)
+    listed = int(packed.launch(s["w2c"], H_inv=hinv)["status"].cpu()[0])     # tile instances listed (after the alpha-footprint cut)
+    sc = _scorer(s, gpu, 4, 64)                                               # far too short: the first launch overflows
+    r = sc.launch(s["w2c"], H_inv=hinv)
+    st = r["status"].cpu().numpy()
+    assert st[1] == 1 and st[3] == 1 and st[2] > 64 and st[0] == listed
+    Hacc = torch.zeros((s["P"], 4), device=gpu)
+    sc.launch(s["w2c"], out_H=Hacc)
+    assert float(Hacc.abs().max()) == 0.0                                       # overflow: nothing accumulated
+    got = sc.run(s["w2c"], H_inv=hinv)                                          # grows to 1.25 x the longest list, repeats
+    assert sc.tile_capacity >= int(st[2]) and sc.tile_capacity % 1024 == 0
+    assert torch.equal(got["scores"], want["scores"])
+    # segments that could never fit: back to packed lists
+    sc2 = _scorer(s, gpu, 4, 64)
+    sc2.MAX_KEY_BYTES_PER_VIEW = 1 << 16
+    got2 = sc2.run(s["w2c"], H_inv=hinv)
+    assert sc2.tile_capacity == 0 and torch.equal(got2["scores"], want["scores"])
+
+
+def test_segments_beyond_the_key_buffer_are_refused(scene, gpu):
+    from fisher_rast import _lib
+    from fisher_rast.ops import FisherCfg
+    s = scene
+    sc = _scorer(s, gpu, 4, 0)
+    V, P = s["V"], s["P"]
+    hinv = s["H_inv"][:, :4].contiguous()
+    max_rendered = V * sc.per_view_capacity
+    ws = torch.empty((int(sc.lib.fr_fisher_workspace_bytes(P, s["W"], s["H"], V, max_rendered, 4)),), dtype=torch.uint8, device=gpu)
+    scores = torch.empty((V,), device=gpu)
+    status = torch.zeros((4,), dtype=torch.int32, device=gpu)
+    fc = FisherCfg()
+    fc.n_views, fc.columns, fc.dL_dpix = V, 4, 1e-3
+    fc.w2c = ctypes.c_void_p(s["w2c"].data_ptr())
+    fc.H_inv = ctypes.c_void_p(hinv.data_ptr())
+    fc.out_scores = ctypes.c_void_p(scores.data_ptr())
+    fc.tile_capacity = max_rendered // (V * 256) + 1
+    rc = sc.lib.fr_fisher_views(ctypes.byref(sc.cfg), ctypes.byref(sc.g), ctypes.byref(fc), ws.data_ptr(), ws.numel(), max_rendered,
+                                status.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream))
+    assert rc != 0 and "tile_capacity" in sc.lib.fr_last_error().decode()
+    with pytest.raises(_lib.FisherRastError):
+        _lib.check(rc, "fr_fisher_views")
