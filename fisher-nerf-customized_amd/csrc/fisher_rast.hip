@@ -103,7 +103,9 @@ struct FrParams {
 	uint32_t* tile_cnt; uint32_t* tile_off; uint32_t* tile_fill; // [V][T]
 	uint64_t* keys; long long key_capacity;
 	uint32_t* blk_base;          // [V][gridDim.x][T] or null: start of each preprocess workgroup's range inside a tile segment
-	uint32_t* big_list;          // [0] = number of tiles with more than FR_SORT_SMALL_KEYS splats, [16..] their (view*T + tile)
+	uint32_t* big_list;          // [0] = number of tiles with more than FR_SORT_SMALL_KEYS splats, [1] = k_tile_lists' finished-block count, [16..] the tiles (view*T + tile)
+	uint32_t* view_work;         // [V] tile instances listed per view, or null  } the balanced deal of the views over the XCDs
+	uint32_t* view_perm;         // [V] (round * 8 + XCD) -> view, or null        } (fr_deal_views / fr_tile_of_block)
 	int* status;                 // [4]
 	int* vis_count;              // [V] or null
 	int* num_rendered;           // [V] or null
@@ -291,12 +293,37 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 	}
 }
 
+// The XCD-aware tile map (fr_tile_of_block) gives every XCD whole views, eight rounds of one view per XCD for 64 views.  Views differ
+// several-fold in their tile instances (61k .. 513k on the bench workload), so dealt in index order (view v -> XCD v mod 8) the XCDs'
+// shares differ and the walk ends with most XCDs idle.  Here the views are ranked by their listed instances and dealt in a snake
+// (round r: ranks 8r .. 8r+7 to XCDs 0..7, the next round 7..0), heaviest round first.  perm[r * 8 + x] = the view XCD x walks in
+// round r.  One workgroup; V <= 1024 (beyond that, and for V % 8 != 0, the map stays the plain one).
+__device__ __forceinline__ void fr_deal_views(const uint32_t* __restrict__ work, uint32_t* __restrict__ perm, int V, int tid, int nthreads)
+{
+	__shared__ uint32_t s_work[1024];
+	for (int v = tid; v < V; v += nthreads) s_work[v] = __hip_atomic_load(work + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (other workgroups' atomic adds: read at the L2)
+	__syncthreads();
+	for (int v = tid; v < V; v += nthreads)
+	{
+		const uint32_t w = s_work[v];
+		int rank = 0;
+		for (int u = 0; u < V; u++)
+		{
+			const uint32_t wu = s_work[u];
+			rank += (wu > w || (wu == w && u < v)) ? 1 : 0;
+		}
+		const int r = rank >> 3, j = rank & 7;
+		perm[r * 8 + ((r & 1) ? 7 - j : j)] = (uint32_t)v;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Exclusive scan of N = V*T tile counts (one block).  status = {total, overflow, max tile count, 0}.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
                                                      uint32_t* __restrict__ fill, int N, int T, int V,
                                                      long long capacity, int* __restrict__ status,
-                                                     int* __restrict__ num_rendered, uint32_t* __restrict__ big_list)
+                                                     int* __restrict__ num_rendered, uint32_t* __restrict__ big_list,
+                                                     uint32_t* __restrict__ view_work, uint32_t* __restrict__ view_perm)
 {
 	__shared__ uint32_t wsum[16];
 	__shared__ uint32_t chunk_total;
@@ -404,14 +431,34 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 			num_rendered[v] = (int)(b - a);
 		}
 	}
+	if (view_perm)
+	{
+		__syncthreads();
+		for (int v = tid; v < V; v += 1024)
+		{
+			uint32_t a = off[(size_t)v * T];
+			uint32_t b = (v + 1 < V) ? off[(size_t)(v + 1) * T] : carry;
+			view_work[v] = b - a;
+		}
+		__syncthreads();
+		fr_deal_views((const uint32_t*)view_work, view_perm, V, tid, 1024);
+	}
 }
 
 // Fixed key segments (FrParams::tile_cap): nothing to scan.  off[i] = i tile_cap, the list of long tiles, and the status word
 // {total, a tile over its capacity, longest list, the same flag} by atomics on the zero-filled words; four tiles per thread.
-__global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int N, uint32_t tile_cap,
-                                                           int* __restrict__ status, uint32_t* __restrict__ big_list, int ablate)
+__global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int N, int T, uint32_t tile_cap,
+                                                           int* __restrict__ status, uint32_t* __restrict__ big_list,
+                                                           uint32_t* __restrict__ view_work, uint32_t* __restrict__ view_perm, int ablate)
 {
 	const int i0 = (blockIdx.x * FR_THREADS + threadIdx.x) * 4;
+	// per-view sums: in LDS first (a block's 1024 tiles span 1024 / T + 1 views at most), then one global add per view and block
+	__shared__ uint32_t s_vw[4 * FR_THREADS + 2];
+	const int vfirst = (blockIdx.x * 4 * FR_THREADS) / T;
+	const int ilast = min(N - 1, (int)(blockIdx.x * 4 * FR_THREADS) + 4 * FR_THREADS - 1);
+	const int nvb = view_work ? ilast / T - vfirst + 1 : 0;
+	for (int k = threadIdx.x; k < nvb; k += FR_THREADS) s_vw[k] = 0u;
+	__syncthreads();
 	uint32_t sum = 0, mx = 0;
 #pragma unroll
 	for (int q = 0; q < 4; q++)
@@ -423,7 +470,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __res
 		sum += c;
 		mx = c > mx ? c : mx;
 		if (c > (uint32_t)FR_SORT_SMALL_KEYS) big_list[16 + atomicAdd(&big_list[0], 1u)] = (uint32_t)i;
+		if (view_work && c) atomicAdd(&s_vw[i / T - vfirst], c);
 	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < nvb; k += FR_THREADS) if (s_vw[k]) atomicAdd(&view_work[vfirst + k], s_vw[k]);
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1)
 	{
@@ -437,6 +487,20 @@ __global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __res
 		if (mx) atomicMax(&status[2], (int)mx);
 		if (mx > tile_cap) { atomicOr(&status[1], 1); atomicOr(&status[3], 1); }
 		FR_ABL(if (ablate >= 30) atomicOr(&status[1], 1);)
+	}
+	if (view_perm)
+	{
+		// the block that finishes last deals the views (its reads of view_work follow every other block's adds: fence + counter)
+		__shared__ bool s_last;
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0) s_last = atomicAdd(&big_list[1], 1u) == gridDim.x - 1;
+		__syncthreads();
+		if (s_last)
+		{
+			__threadfence();
+			fr_deal_views((const uint32_t*)view_work, view_perm, N / T, threadIdx.x, FR_THREADS);
+		}
 	}
 }
 
@@ -1248,6 +1312,7 @@ __device__ __forceinline__ void fr_tile_of_block(const FrParams& p, uint32_t& ti
 	{
 		const uint32_t xcd = L & 7u, q = L >> 3;
 		v = (int)((q / (uint32_t)p.T) * 8u + xcd);
+		if (p.view_perm) v = (int)p.view_perm[v];           // views dealt by weight (fr_deal_views)
 		tile = q % (uint32_t)p.T;
 	}
 	else
@@ -5203,6 +5268,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	{
 		FrZeroer z;
 		z.add(p.tile_cnt, (size_t)p.V * p.T * 4); z.add(p.status, 16); z.add(p.big_list, 64);
+		if (p.view_work) z.add(p.view_work, (size_t)p.V * 4);
 		if (p.vis_count) z.add(p.vis_count, (size_t)p.V * 4);
 		if (p.num_rendered && p.vis_list != nullptr && p.T <= FR_MAX_LDS_TILES) z.add(p.num_rendered, (size_t)p.V * 4);   // counted by k_preprocess_views
 		z.launch(s);
@@ -5266,11 +5332,11 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		if ((rc = fr_check_launch("k_preprocess"))) return rc;
 	}
 	if (multi && p.tile_cap)
-		hipLaunchKernelGGL(k_tile_lists, dim3((p.V * p.T + 4 * FR_THREADS - 1) / (4 * FR_THREADS)), dim3(FR_THREADS), 0, s, p.tile_cnt, p.tile_off, p.V * p.T,
-		                   p.tile_cap, p.status, p.big_list, p.ablate);
+		hipLaunchKernelGGL(k_tile_lists, dim3((p.V * p.T + 4 * FR_THREADS - 1) / (4 * FR_THREADS)), dim3(FR_THREADS), 0, s, p.tile_cnt, p.tile_off, p.V * p.T, p.T,
+		                   p.tile_cap, p.status, p.big_list, p.view_work, p.view_perm, p.ablate);
 	else
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
-	                   p.key_capacity, p.status, multi ? (int*)nullptr : p.num_rendered, p.big_list);
+	                   p.key_capacity, p.status, multi ? (int*)nullptr : p.num_rendered, p.big_list, p.view_work, p.view_perm);
 	if ((rc = fr_check_launch("k_scan_tiles"))) return rc;
 	if (multi && p.tile_cap) { /* the projection kernel has placed the keys */ }
 	else if (multi) hipLaunchKernelGGL(k_scatter_vis, gridP, dim3(FR_THREADS), 2 * hist_lds, s, p);
@@ -5623,7 +5689,7 @@ static int fr_debug_mode()
 
 #define FR_MAX_GROUPS 4              // view groups of one fr_fisher_views call (fr_pick_groups)
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
 	size_t PV;                   // slots per view of the compact records: projection workgroups * 256 G (>= P)
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
@@ -5646,6 +5712,8 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
 	L.cov_trace = o; o = fr_align(o + (size_t)P * 4);
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64 * FR_MAX_GROUPS);      // one {count, pad[15], list} per view group
+	L.view_work = o; o = fr_align(o + (size_t)V * 4);
+	L.view_perm = o; o = fr_align(o + (size_t)V * 4);
 	L.blk_base = o; o = fr_align(o + (size_t)V * (size_t)fr_preprocess_blocks(P, V) * (size_t)T * 4);
 	L.cov3D = o; o = fr_align(o + (size_t)P * 24);
 	L.tile_cnt = o; o = fr_align(o + (size_t)(V * T) * 4);
@@ -5811,6 +5879,10 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	p.tile_fill = (uint32_t*)(ws + L.tile_fill);
 	p.status = (int*)(ws + L.status);
 	p.big_list = (uint32_t*)(ws + L.big_list);
+	// the views dealt over the XCDs by weight (FR_DEBUG_MODE=27: in index order, for A/B runs)
+	const bool deal = (V & 7) == 0 && V <= 1024 && fr_debug_mode() != 27;
+	p.view_work = deal ? (uint32_t*)(ws + L.view_work) : nullptr;
+	p.view_perm = deal ? (uint32_t*)(ws + L.view_perm) : nullptr;
 	p.blk_base = (uint32_t*)(ws + L.blk_base);
 	p.keys = (uint64_t*)(ws + L.keys);
 	p.key_capacity = max_rendered;
@@ -5905,6 +5977,8 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		pg.tile_cnt = p.tile_cnt + (size_t)v0 * p.T; pg.tile_off = p.tile_off + (size_t)v0 * p.T; pg.tile_fill = p.tile_fill + (size_t)v0 * p.T;
 		pg.status = p.status + 4 * gi;
 		pg.big_list = p.big_list + (size_t)v0 * p.T + 16 * gi;
+		if (p.view_perm && (Vg & 7) == 0) { pg.view_work = p.view_work + v0; pg.view_perm = p.view_perm + v0; }
+		else { pg.view_work = nullptr; pg.view_perm = nullptr; }
 		pg.blk_base = p.blk_base + (size_t)v0 * (size_t)fr_preprocess_blocks(P, V) * (size_t)p.T;
 		pg.tile_cap = p.tile_cap;                                  // (fr_bin_pipeline clears it where the front end cannot fill fixed segments)
 		const long long k0 = (long long)((__int128)max_rendered * v0 / V), k1 = (long long)((__int128)max_rendered * (v0 + Vg) / V);
