@@ -1084,6 +1084,27 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 					}
 				}
 				uint32_t* h = hist + (size_t)vv * p.T;
+				if constexpr (DK)
+				{
+					// Fixed segments: the keys also say which of the tile's four 16 x 4 strips the footprint [px -+ hx] x [py -+ hy]
+					// reaches (the test a wave of the tile kernels would otherwise make per key, from a gathered record), so
+					// the rectangle is kept in strip rows from here on, cut to the strips / tile columns that test admits.
+					const float hx = __half2float(__ushort_as_half((unsigned short)(ext & 0xffffu)));
+					const float hy = __half2float(__ushort_as_half((unsigned short)(ext >> 16)));
+					ry0 *= 4u; ry1 *= 4u;
+					if (hx >= 0.f && hx < 1e30f && rx1 > rx0 && ry1 > ry0)
+					{
+						const int tx0 = (int)ceilf((sp.px - hx - 15.0f) * 0.0625f), sy0 = (int)ceilf((sp.py - hy - 3.0f) * 0.25f);
+						const int sy1 = (int)floorf((sp.py + hy) * 0.25f) + 1;
+						rx0 = (uint32_t)max((int)rx0, tx0); rx1 = max(rx0, rx1);
+						ry0 = (uint32_t)max((int)ry0, sy0); ry1 = (uint32_t)max((int)ry0, min((int)ry1, sy1));
+					}
+					if (rx1 > rx0 && ry1 > ry0)
+						for (uint32_t y = ry0 >> 2; y <= (ry1 - 1u) >> 2; y++)
+							for (uint32_t x = rx0; x < rx1; x++)
+								atomicAdd(&h[y * p.gx + x], 1u);
+				}
+				else
 				for (uint32_t y = ry0; y < ry1; y++)
 					for (uint32_t x = rx0; x < rx1; x++)
 						atomicAdd(&h[y * p.gx + x], 1u);
@@ -1126,8 +1147,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				else fr_fisher_record_one<C, false, (AF == 1)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
 				if constexpr (DK)
 				{
-					// 8-byte list entry {depth, x0 | y0 << 8 | width << 16 | height << 24} (tile grids up to 255 x 255: fr_fisher_views);
-					// the slot is the entry's place in the list
+					// 8-byte list entry {depth, x0 | y0 << 8 | width << 16 | height << 24}, y0 / height in strip rows (tile grids up to
+					// 255 x 63: fr_fisher_views); the slot is the entry's place in the list
 					const uint32_t xy0 = park[10 * FR_THREADS + r], xy1 = park[11 * FR_THREADS + r];
 					const uint32_t rect = (xy0 & 255u) | ((xy0 >> 16) << 8) | (((xy1 & 0xffffu) - (xy0 & 0xffffu)) << 16) | (((xy1 >> 16) - (xy0 >> 16)) << 24);
 					((uint2*)p.vis_list)[((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)] = make_uint2(park[9 * FR_THREADS + r], rect);
@@ -1169,7 +1190,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				for (int k = 0; k < FR_VC_MAX - 1; k++) if (e >= vend[k]) { vv = k + 1; lo = vend[k]; }
 				dv[b] = vv;
 				de[b] = make_uint2(0u, 0u);                                  // empty rect
-				FR_ABL(if (p.ablate == 33) { if (e < ntot) de[b] = make_uint2(e, (e & 7u) | ((e >> 3 & 15u) << 8) | (2u << 16) | (1u << 24)); } else)
+				FR_ABL(if (p.ablate == 33) { if (e < ntot) de[b] = make_uint2(e, (e & 7u) | ((e >> 3 & 15u) << 10) | (2u << 16) | (2u << 24)); } else)
 				if (e < ntot) de[b] = ((const uint2*)p.vis_list)[((size_t)(v0 + vv) * nblk + blockIdx.x) * cap + (e - lo)];
 			}
 		};
@@ -1213,23 +1234,29 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 #pragma unroll
 			for (int b = 0; b < NB; b++)
 			{
-				// the slot is the entry's place in its list: the keys carry it (monotone in the Gaussian index)
+				// key = depth | slot << 4 | strips: the slot is the entry's place in its list (monotone in the Gaussian index, so ties of
+				// equal depth sort like the reference's), the low four bits say which strips of THIS tile the footprint reaches
 				const uint32_t e = e0 + b * FR_THREADS + tid;
 				const uint32_t lo = ev[b] ? vend[ev[b] - 1] : 0u;
-				const uint64_t key = ((uint64_t)en[b].x << 32) | (blockIdx.x * cap + (e - lo));
+				const uint64_t key = ((uint64_t)en[b].x << 32) | ((blockIdx.x * cap + (e - lo)) << 4);
 				const uint32_t r = en[b].y;
-				const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = x0 + ((r >> 16) & 255u), y1 = y0 + (r >> 24);
+				const uint32_t x0 = r & 255u, s0 = (r >> 8) & 255u, x1 = x0 + ((r >> 16) & 255u), s1 = s0 + (r >> 24);     // strip rows [s0, s1)
 				const uint32_t* hb = hist + (size_t)ev[b] * p.T;
 				uint32_t* cu = cursor + (size_t)ev[b] * p.T;
-				for (uint32_t y = y0; y < y1; y++)
+				if (x1 > x0 && s1 > s0)
+				for (uint32_t y = s0 >> 2; y <= (s1 - 1u) >> 2; y++)
+				{
+					const uint32_t a = max(s0, 4u * y) - 4u * y, z = min(s1, 4u * y + 4u) - 4u * y;      // strips [a, z) of tile row y
+					const uint64_t ky = key | (uint64_t)(((1u << z) - 1u) & ~((1u << a) - 1u));
 					for (uint32_t x = x0; x < x1; x++)
 					{
 						const uint32_t t = y * p.gx + x;
 						const uint32_t base = hb[t];
 						const uint32_t k = atomicAdd(&cu[t], 1u);
 						FR_ABL(if (p.ablate != 32 && p.ablate != 33))
-						if (base != 0xffffffffu) p.keys[base + k] = key;
+						if (base != 0xffffffffu) p.keys[base + k] = ky;
 					}
+				}
 			}
 			if (more)
 			{
@@ -1966,6 +1993,7 @@ struct FrFisherArgs {
 	float* tile_scores;          // [V][T] partial sums, reduced in fixed order by k_reduce_scores
 	const uint8_t* only_flagged; // [V][T] or null: when set, k_fisher_tile handles only the flagged tiles
 	int debug_mode;              // FR_DEBUG_MODE env (timing ablations only): 1 = k_fisher_tile_v2 stops after pass 1
+	int key_shift;               // 0: keys = depth | index; 4: keys = depth | slot << 4 | strips (fixed key segments: k_preprocess_views_c<.., true>)
 	// the scorer's records as k_fisher_tile_v3 / _v3h address them: record r of view v has {recA, recB} at recA[v * ab_view + r * ab_stride]
 	// (+ 1) and its four recQ float4 at recQ[v * q_view + r * q_stride + k] -- two dense [V][P] arrays (strides 2 and 4), or the
 	// compact 96-byte records (both strides 6, r = slot); slot_idx [V][slot_view] maps a slot back to the Gaussian index, or null
@@ -3054,13 +3082,16 @@ __device__ __forceinline__ bool fr_walk_update(const FrWalkGeom& g, bool live, f
 //           test, the transmittance / colour prefix recurrences and the three sums.  A finished pixel clears its masks;
 //           a wave whose 64 pixels are finished leaves.
 // BW x BH = the 64 pixels of a wave inside the 16 x 16 tile: 16 x 4 strips (used), or 8 x 8 blocks (5 % slower on MI355X).
-template <int BW, int BH>
+// MK: the keys carry, in their low four bits, the strips of the tile their splat's footprint reaches (fixed key segments; the
+// front end has made the stream step's test once per (splat, tile)): a wave keeps the keys with ITS bit -- no recA gather per key.
+template <int BW, int BH, bool MK = false>
 #ifndef FR_V3_WAVES
 #define FR_V3_WAVES 5
 #endif
 __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, FR_V3_WAVES)))
 void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
 {
+	static_assert(!MK || (BW == 16 && BH == 4), "the keys' strip bits are those of 16 x 4 strips");
 	static_assert(BW * BH == 64 && 16 % BW == 0, "a wave owns 64 pixels of the tile");
 	__shared__ uint32_t s_q[4][FR_QCAP];
 	__shared__ float4 s_ent[4][64][FR_ENT3_F4];
@@ -3103,7 +3134,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	// software pipeline of the key stream: id1 / r1 = indices and recA of the chunk at `base`, id2 = indices of the next one
 	uint32_t id1 = 0, id2 = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-	if ((uint32_t)lane < n) { id1 = (uint32_t)FR_LDK(gk + lane); r1 = rec[rsA * id1]; }
+	if ((uint32_t)lane < n) { id1 = (uint32_t)FR_LDK(gk + lane); if constexpr (!MK) r1 = rec[rsA * id1]; }
 	if (64u + lane < n) id2 = (uint32_t)FR_LDK(gk + 64 + lane);
 	uint32_t base = 0;
 	// ---- stream: fill the queue up to one chunk
@@ -3115,15 +3146,19 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 		{
 			const uint32_t idc = id1; const float4 rc = r1;
 			id1 = id2;
-			if (base + 64 + lane < n) r1 = rec[rsA * id2];
+			if constexpr (!MK) { if (base + 64 + lane < n) r1 = rec[rsA * id2]; }
 			if (base + 128 + lane < n) id2 = (uint32_t)FR_LDK(gk + base + 128 + lane);
-			const uint32_t eb = __float_as_uint(rc.z);
-			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
-			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
-			const bool ov = (base + lane < n) && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi)
-			                && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			bool ov = base + lane < n;
+			if constexpr (MK) ov = ov && ((idc >> wave) & 1u);
+			else
+			{
+				const uint32_t eb = __float_as_uint(rc.z);
+				const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+				const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+				ov = ov && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi) && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			}
 			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
-			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc;
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = MK ? (idc >> 4) : idc;
 			qn += (uint32_t)__popcll(om);
 			base += 64;
 		}
@@ -3705,13 +3740,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 template <int BW, int BH, int NQ, class Body, int EF4 = FR_ENT_F4>
 __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, uint32_t n, const float4* __restrict__ rec, size_t sA,
                                               const float4* __restrict__ rq, size_t sQ, uint32_t* wq, float4 (*ent)[EF4],
-                                              int lane, float strip_lo, float tile_x0, bool& done, Body body)
+                                              int lane, float strip_lo, float tile_x0, int kshift, int wave, bool& done, Body body)
 {
+	// kshift = 4: keys = depth | slot << 4 | strips (fixed key segments) -- the wave keeps the keys with its bit, no gather per key
 	const float strip_hi = strip_lo + (float)(BH - 1), tile_x1 = tile_x0 + (float)(BW - 1);
 	uint32_t qh = 0, qn = 0;
 	uint32_t id1 = 0, id2 = 0;
 	float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; r1 = rec[sA * id1]; }
+	if ((uint32_t)lane < n) { id1 = (uint32_t)gk[lane]; if (!kshift) r1 = rec[sA * id1]; }
 	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
 	uint32_t base = 0;
 	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
@@ -3721,15 +3757,19 @@ __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, u
 		{
 			const uint32_t idc = id1; const float4 rc = r1;
 			id1 = id2;
-			if (base + 64 + lane < n) r1 = rec[sA * id2];
+			if (!kshift && base + 64 + lane < n) r1 = rec[sA * id2];
 			if (base + 128 + lane < n) id2 = (uint32_t)gk[base + 128 + lane];
-			const uint32_t eb = __float_as_uint(rc.z);
-			const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
-			const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
-			const bool ov = (base + lane < n) && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi)
-			                && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			bool ov = base + lane < n;
+			if (kshift) ov = ov && ((idc >> wave) & 1u);
+			else
+			{
+				const uint32_t eb = __float_as_uint(rc.z);
+				const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+				const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+				ov = ov && hx >= 0.f && (rc.y + hy >= strip_lo) && (rc.y - hy <= strip_hi) && (rc.x + hx >= tile_x0) && (rc.x - hx <= tile_x1);
+			}
 			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
-			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc;
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc >> kshift;
 			qn += (uint32_t)__popcll(om);
 			base += 64;
 		}
@@ -3796,7 +3836,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	float T = 1.0f;
 	double Cg = 0.0;
 	bool done = !inside;
-	fr_strip_pass<BW, BH, 0>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done,
+	fr_strip_pass<BW, BH, 0>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done,
 		[&](uint32_t, uint32_t, unsigned long long emask) {
 			unsigned long long mask = fr_wave_transpose64(emask, lane);
 			if (done) mask = 0ull;
@@ -3847,7 +3887,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 		}
 		return kill;
 	};
-	fr_strip_pass<BW, BH, 4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done,
+	fr_strip_pass<BW, BH, 4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done,
 		[&](uint32_t m, uint32_t my_id, unsigned long long emask) {
 #pragma unroll
 			for (int c = 0; c < 4; c++) acc[c][lane] = 0.0;
@@ -3950,7 +3990,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFi
 			if (fr_prefix_update(g, cgz, T, Cg, con)) { mask = 0ull; done = true; }
 		}
 	};
-	fr_strip_pass<16, 4, NQ, decltype(pass1), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done, pass1);
+	fr_strip_pass<16, 4, NQ, decltype(pass1), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done, pass1);
 	const float bgz = IMG ? (z0 * p.bg[0] + z1 * p.bg[1] + z2 * p.bg[2]) : (p.bg[0] + p.bg[1] + p.bg[2]);
 	const double X = Cg + (double)(T * bgz);
 
@@ -4022,7 +4062,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFi
 		}
 		__builtin_amdgcn_wave_barrier();
 	};
-	fr_strip_pass<16, 4, NQ, decltype(pass2), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, done, pass2);
+	fr_strip_pass<16, 4, NQ, decltype(pass2), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done, pass2);
 }
 
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
@@ -5762,6 +5802,7 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 	// FR_DEBUG_MODE=24: the rolling two-chunk window (k_fisher_tile_v3w: 24 % fewer walk iterations, 8 % slower -- see there)
 	if (f.debug_mode == 8) hipLaunchKernelGGL((k_fisher_tile_v3<8, 8>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	else if (f.debug_mode == 24) hipLaunchKernelGGL(k_fisher_tile_v3w, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f);
+	else if (f.key_shift) hipLaunchKernelGGL((k_fisher_tile_v3<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	else hipLaunchKernelGGL((k_fisher_tile_v3<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	if (g_prof_on)
 	{
@@ -5892,7 +5933,11 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		// fixed key segments: V T tile_capacity keys must fit the key buffer (and 32-bit offsets)
 		const long long need = (long long)V * p.T * (long long)fc->tile_capacity;
 		if (need > max_rendered || need >= (1ll << 32)) return fr_fail(FR_EINVAL, "fr_fisher_views: n_views * tiles * tile_capacity exceeds max_rendered (or 2^32)");
-		if (p.gx <= 255u && p.gy <= 255u) p.tile_cap = (uint32_t)fc->tile_capacity;      // (the 8-byte list entries hold tile coordinates in bytes; else: packed lists)
+		// (else packed lists: the 8-byte list entries hold tile columns and strip rows in bytes, the keys 28-bit record slots;
+		// FR_DEBUG_MODE 8 / 24: tile kernels that do not read the keys' strip bits)
+		const long long nblk_c = (P + FR_THREADS * fr_pick_G_views(P) - 1) / (FR_THREADS * fr_pick_G_views(P));
+		const bool slots_fit = nblk_c * FR_THREADS * fr_pick_G_views(P) < (1ll << 28);
+		if (p.gx <= 255u && p.gy <= 63u && slots_fit && fr_debug_mode() != 8 && fr_debug_mode() != 24) p.tile_cap = (uint32_t)fc->tile_capacity;
 	}
 	p.vis_count = fc->out_vis_count;
 	p.num_rendered = fc->out_num_rendered;
@@ -5904,6 +5949,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	f.tile_scores = (float*)(ws + L.tile_scores);
 	f.only_flagged = nullptr;
 	f.debug_mode = fr_debug_mode();
+	f.key_shift = 0;
 	// score-only (H_inv, no out_H, constant upstream gradient): records + one front-to-back pass; FR_DEBUG_MODE=9 keeps
 	// the second-generation two-pass kernel for A/B runs
 	const bool v3 = fc->H_inv && !fc->out_H && !fc->dL_dpix_image && f.debug_mode != 1 && f.debug_mode != 9;
@@ -6000,6 +6046,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		if (f.dL_img && f.dL_stride) fg.dL_img = f.dL_img + (size_t)v0 * f.dL_stride;
 
 		if ((rc = fr_bin_pipeline(pg, g, s, (v3 || v3h || v3g) ? &pl : nullptr))) return rc;
+		fg.key_shift = pg.tile_cap ? 4 : 0;                          // (fixed segments: k_preprocess_views_c<.., true> wrote depth | slot << 4 | strips)
 		if (use_side)
 		{
 			if (!front_done[gi] && hipEventCreateWithFlags(&front_done[gi], hipEventDisableTiming) != hipSuccess)

@@ -1,6 +1,6 @@
 """-m gpu: the two key layouts of fr_fisher_views -- packed lists (count, scan, scatter kernel; fr_fisher_cfg.tile_capacity = 0)
 and fixed per-(view, tile) segments filled by the projection kernel itself (tile_capacity > 0, the scorer's default).  The sorted
-lists are the same lists, so scores are bit-identical; a list longer than its segment raises the overflow flag, nothing is
+lists hold the same contributing splats in the same order, so scores are bit-identical; a list longer than its segment raises the overflow flag, nothing is
 scored or accumulated, and FisherScorer.run grows the segments (or goes back to packed lists) and repeats the launch."""
 import ctypes
 
@@ -60,7 +60,8 @@ def test_a_list_longer_than_its_segment_grows_the_segments(scene, gpu):
     sc = _scorer(s, gpu, 4, 64)                                               # far too short: the first launch overflows
     r = sc.launch(s["w2c"], H_inv=hinv)
     st = r["status"].cpu().numpy()
-    assert st[1] == 1 and st[3] == 1 and st[2] > 64 and st[0] == listed
+    # (fixed segments list a tile only where the footprint test of the tile kernel's waves admits one of its strips: a few keys fewer)
+    assert st[1] == 1 and st[3] == 1 and st[2] > 64 and 0.9 * listed < st[0] <= listed
     Hacc = torch.zeros((s["P"], 4), device=gpu)
     sc.launch(s["w2c"], out_H=Hacc)
     assert float(Hacc.abs().max()) == 0.0                                       # overflow: nothing accumulated
