@@ -907,16 +907,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 {
 	static_assert((C == 4 || C == 11) && AF >= 0 && AF <= 2 && !(AF == 1 && C != 4), "records modes: score form, A-form (4 columns), general out_H form");
 	constexpr int RS = FrRecStride<C, AF>::value;     // float4 per compact record
-	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * VC] | wm[VC][12] | park[13][FR_THREADS] | DK: cursor[VC][T]
+	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * (VC + 1)] | wm[VC][12] | park[13][FR_THREADS] | DK: cursor[VC][T]
 	const int VC = p.VC;
 	uint32_t* hist = fr_dyn_lds;
 	uint32_t* pairs = hist + (size_t)VC * p.T;
-	float* s_wm = (float*)(pairs + FR_THREADS * VC);
+	float* s_wm = (float*)(pairs + FR_THREADS * (VC + 1));
 	uint32_t* park = (uint32_t*)(s_wm + 12 * VC);
 	__shared__ uint32_t s_n[FR_VC_MAX];          // visible pairs per view so far = the next slot of the view
 	__shared__ uint32_t s_ref[FR_VC_MAX];
 	__shared__ uint32_t s_ca[FR_VC_MAX * 4];     // phase A: survivors per (view, wave)
-	__shared__ uint32_t s_bv[FR_VC_MAX];         // visible pairs per view of the current batch
+	__shared__ uint32_t s_wk[FR_VC_MAX * 4];     // visible pairs per (view, wave) of the current batch
 	__shared__ uint32_t s_wtot[4];               // ... per wave
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -927,19 +927,25 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 	for (int t = tid; t < nv * p.T; t += FR_THREADS) hist[t] = 0;
 	const bool has_w2c = p.w2c != nullptr;
 	if (has_w2c) for (int t = tid; t < nv * 12; t += FR_THREADS) s_wm[t] = p.w2c[16 * (size_t)(v0 + t / 12) + (t % 12)];
-	if (tid < FR_VC_MAX) { s_n[tid] = 0; s_ref[tid] = 0; s_bv[tid] = 0; }
+	if (tid < FR_VC_MAX) { s_n[tid] = 0; s_ref[tid] = 0; }
 	float vm[16], pm[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) { vm[k] = p.view[k]; pm[k] = p.proj[k]; }
 	const size_t PV = (size_t)nblk * cap;
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	__syncthreads();
+	// Survivors wait in `pairs` until 256 of them make a full batch for phases B and C (one 256-Gaussian round leaves ~290 on the
+	// bench workload: a full batch and a nearly empty one, had every round been flushed by itself); what is left over after a round
+	// (< 256) moves to the front of the list, the last round flushes.  A pending entry = index inside the workgroup's share | view << 16.
+	const int iw = blockIdx.x * p.G * FR_THREADS;       // the workgroup's first Gaussian
+	uint32_t pend = 0;                                  // survivors waiting, uniform
 	for (int g = 0; g < p.G; g++)
 	{
-		const int i0 = (blockIdx.x * p.G + g) * FR_THREADS;
+		const int i0 = iw + g * FR_THREADS;
 		if (i0 >= p.P) break;
+		const bool last_round = g == p.G - 1 || i0 + FR_THREADS >= p.P;
 		uint32_t np = 0;
-		// ---- phase A (the tests of k_preprocess_views): near-plane + early frustum test, survivors compacted into `pairs`
+		// ---- phase A (the tests of k_preprocess_views): near-plane + early frustum test, survivors appended to `pairs`
 		{
 			const int i = i0 + tid;
 			const bool live = i < p.P;
@@ -1001,15 +1007,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				const bool keep = (keepbits >> vv) & 1u;
 				const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
 				const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)exc, vv * 4 + wave);
-				if (keep) pairs[base + (uint32_t)__popcll(m & lt)] = (uint32_t)tid | ((uint32_t)vv << 8);
+				if (keep) pairs[pend + base + (uint32_t)__popcll(m & lt)] = (uint32_t)(g * FR_THREADS + tid) | ((uint32_t)vv << 16);
 			}
 		}
 		__syncthreads();
 		FR_ABL(if (p.ablate == 35) np = 0;)                      // 35: phase A only
-		for (uint32_t e0 = 0; e0 < np; e0 += FR_THREADS)
+		pend += np;
+		const uint32_t ndo = last_round ? pend : (pend & ~(uint32_t)(FR_THREADS - 1));     // whole batches, all of it in the last round
+		for (uint32_t e0 = 0; e0 < ndo; e0 += FR_THREADS)
 		{
 			const uint32_t e = e0 + (uint32_t)tid;
-			const bool active = e < np;
+			const bool active = e < ndo;
 			// ---- phase B: projection of one survivor
 			int i = 0, vv = 0;
 			fr_splat sp;
@@ -1019,8 +1027,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			if (active)
 			{
 					const uint32_t pr = pairs[e];
-				i = i0 + (int)(pr & 255u);
-				vv = (int)(pr >> 8);
+				i = iw + (int)(pr & 0xffffu);
+				vv = (int)(pr >> 16);
 				constexpr int PSB = FrPackSize<C>::value;
 				const float4* pk = (const float4*)(ra.packed + (size_t)i * PSB);
 				const float4 t0 = pk[0], t1 = pk[1], t2 = pk[2];
@@ -1039,15 +1047,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				if (sp.radius > 0) { o = p.opac[i]; ext = fr_alpha_extent(sp.conx, sp.cony, sp.conz, o); }
 			}
 			const bool vis = sp.radius > 0;
-			// ---- ordered ranks.  The list is sorted by (view, index), so is every batch: a visible pair's position among the
-			// batch's visible pairs (`pos`: lower waves + lower lanes) minus the batch's visible pairs of the lower views is its rank
-			// among the batch's visible pairs of ITS view; s_n adds the view's pairs of the earlier batches.
+			// ---- ordered ranks.  The pending list is a sequence of rounds, each sorted by (view, index), so the pairs of one view stand
+			// in index order in it, and in every batch: a visible pair's rank among its view's visible pairs is the view's count of the
+			// earlier batches (s_n) + the same-view visible pairs of the lower waves + those of the lower lanes.  `pos` (its place among
+			// ALL visible pairs of the batch) only packs the batch for phase C.
 			const unsigned long long mv = __builtin_amdgcn_ballot_w64(vis);
 			if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(mv);
+			uint32_t below = 0;                                     // same-view visible pairs in the lower lanes of this wave
 			for (int k = 0; k < nv; k++)
 			{
 				const unsigned long long mk = __builtin_amdgcn_ballot_w64(vis && vv == k);
-				if (lane == 0 && mk) atomicAdd(&s_bv[k], (uint32_t)__popcll(mk));
+				if (lane == 0) s_wk[k * 4 + wave] = (uint32_t)__popcll(mk);
+				if (vv == k) below = (uint32_t)__popcll(mk & lt);
 			}
 			__syncthreads();
 			uint32_t rank = 0, pos = 0, nvis = 0;
@@ -1058,12 +1069,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			}
 			if (vis)
 			{
-				uint32_t before = 0;
-				for (int k = 0; k < vv; k++) before += s_bv[k];
-				rank = s_n[vv] + pos - before;
+				rank = s_n[vv] + below;
+				for (int w = 0; w < wave; w++) rank += s_wk[vv * 4 + w];
 			}
-			__syncthreads();                                        // every rank is taken: s_n and s_bv may change
-			if (tid < nv) { s_n[tid] += s_bv[tid]; s_bv[tid] = 0u; }
+			__syncthreads();                                        // every rank is taken: s_n and s_wk may change
+			if (tid < nv) s_n[tid] += (s_wk[tid * 4] + s_wk[tid * 4 + 1]) + (s_wk[tid * 4 + 2] + s_wk[tid * 4 + 3]);
 			if (vis)
 			{
 				// tile rectangle: the reference's radius rectangle (rasterizer_impl.cu:70-111) cut down to the tiles the conservative
@@ -1162,8 +1172,19 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				}
 				if constexpr (AF != 0) ra.slot_idx[(size_t)v * PV + slot] = idx;    // (the out_H kernels go back to the index)
 			}
-			__syncthreads();                                        // park[], s_wtot and s_bv are reused by the next batch
+			__syncthreads();                                        // park[], s_wtot and s_wk are reused by the next batch
 		}
+		// what is left over moves to the front of the list
+		const uint32_t rem = pend - ndo;
+		if (rem != 0u && ndo != 0u)
+		{
+			uint32_t t = 0;
+			if ((uint32_t)tid < rem) t = pairs[ndo + tid];
+			__syncthreads();
+			if ((uint32_t)tid < rem) pairs[tid] = t;
+			__syncthreads();
+		}
+		pend = rem;
 	}
 	if constexpr (DK)
 	{
@@ -5072,9 +5093,10 @@ static inline int fr_pick_G_views(long long P)
 	static int forced = -1;                                   // FR_GV=<n>: A/B runs
 	if (forced < 0) { const char* e = getenv("FR_GV"); forced = e ? atoi(e) : 0; }
 	if (forced > 0) return forced > 8 ? 8 : forced;
-	// ~640 workgroups along P (measured on MI355X, 500k Gaussians x 64 views, ms per step: G = 1: 2.24, 2: 2.20, 3: 2.17-2.20,
-	// 4: 2.19-2.22, 7: 2.26, 10: 2.37 -- the kernel wants two to three rounds of small workgroups, not one of large ones)
-	long long gwant = P / ((long long)FR_THREADS * 640);
+	// ~400 workgroups along P.  (Measured on MI355X, 500k Gaussians x 64 views, ms per step, round 2: G = 1: 2.24, 2: 2.20, 3: 2.17-2.20,
+	// 4: 2.19-2.22, 7: 2.26, 10: 2.37; round 3, with the survivors of the 256-Gaussian rounds batched across rounds and the key
+	// scatter at the end of the workgroup: G = 2: 1.69, 3: 1.69-1.72, 5: 1.67-1.68, 6: 1.68-1.70, 8: 1.68-1.70.)
+	long long gwant = (P + (long long)FR_THREADS * 200) / ((long long)FR_THREADS * 400);
 	return (int)(gwant < 1 ? 1 : (gwant > 8 ? 8 : gwant));
 }
 static inline int fr_pick_VC(long long T)
@@ -5348,7 +5370,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
 		if (!once) p.tile_cap = 0;                       // fixed key segments are filled by k_preprocess_views_c only
 		const bool dk = p.tile_cap != 0;
-		const size_t lds_c = ((size_t)p.VC * p.T * (dk ? 2 : 1) + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
+		const size_t lds_c = ((size_t)p.VC * p.T * (dk ? 2 : 1) + (size_t)FR_THREADS * (p.VC + 1) + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
 		if (once && plan->general && plan->columns == 4 && dk) hipLaunchKernelGGL((k_preprocess_views_c<4, 2, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (once && plan->general && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 2, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (once && plan->general && dk) hipLaunchKernelGGL((k_preprocess_views_c<11, 2, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
