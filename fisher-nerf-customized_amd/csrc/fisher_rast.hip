@@ -3105,11 +3105,13 @@ __device__ __forceinline__ bool fr_walk_update(const FrWalkGeom& g, bool live, f
 // BW x BH = the 64 pixels of a wave inside the 16 x 16 tile: 16 x 4 strips (used), or 8 x 8 blocks (5 % slower on MI355X).
 // MK: the keys carry, in their low four bits, the strips of the tile their splat's footprint reaches (fixed key segments; the
 // front end has made the stream step's test once per (splat, tile)): a wave keeps the keys with ITS bit -- no recA gather per key.
+// Waves per SIMD: 5 with the gathering stream step (6 and 7 measured no faster in round 2); the MK form needs 69 registers and
+// runs 7 (0.745-0.755 ms against 0.785 at 5: the walk is a chain of dependent LDS reads and arithmetic, more waves hide more of it).
 template <int BW, int BH, bool MK = false>
 #ifndef FR_V3_WAVES
 #define FR_V3_WAVES 5
 #endif
-__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, FR_V3_WAVES)))
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, MK ? 7 : FR_V3_WAVES)))
 void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
 {
 	static_assert(!MK || (BW == 16 && BH == 4), "the keys' strip bits are those of 16 x 4 strips");
