@@ -97,3 +97,46 @@ def test_segments_beyond_the_key_buffer_are_refused(scene, gpu):
     assert rc != 0 and "tile_capacity" in sc.lib.fr_last_error().decode()
     with pytest.raises(_lib.FisherRastError):
         _lib.check(rc, "fr_fisher_views")
+
+
+def test_images_taller_than_the_strip_row_byte_fall_back_to_packed_lists(gpu):
+    """The 8-byte list entries of the fixed-segment front end hold strip rows in a byte: beyond 63 tile rows (1008 pixels) the
+    library keeps packed lists whatever tile_capacity says -- same scores, no overflow."""
+    from fisher_rast import synthetic
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    P, V, W, H = 20_000, 8, 64, 1040
+    act = synthetic.activate(synthetic.room_shell(P, seed=9))
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(V, seed=9)).to(gpu)
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    hinv = (torch.rand((P, 4), generator=torch.Generator().manual_seed(6)) + 0.05).to(gpu)
+    args = [act[k].to(gpu) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")]
+    a, b = FisherScorer(cam, *args), FisherScorer(cam, *args)
+    a.tile_capacity = 0
+    assert b.tile_capacity > 0
+    ra, rb = a.run(w2c, H_inv=hinv), b.run(w2c, H_inv=hinv)
+    assert torch.equal(ra["scores"], rb["scores"]) and float(ra["scores"].max()) > 0
+    assert torch.equal(ra["num_rendered"], rb["num_rendered"])
+    st = b.launch(w2c, H_inv=hinv)["status"].cpu()
+    assert int(st[1]) == 0 and int(st[3]) == 0
+
+
+def test_views_that_do_not_fill_the_xcds_and_tiny_maps(gpu):
+    """V % 8 != 0 (no deal of the views over the XCDs), a single view, fewer Gaussians than one projection workgroup holds."""
+    from fisher_rast import synthetic
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    W = H = 128
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    for P, V in ((100, 1), (3000, 5), (3000, 13)):
+        act = synthetic.activate(synthetic.room_shell(P, seed=11))
+        w2c = synthetic.invert_rigid(synthetic.candidate_poses(V, seed=11)).to(gpu)
+        hinv = (torch.rand((P, 4), generator=torch.Generator().manual_seed(7)) + 0.05).to(gpu)
+        args = [act[k].to(gpu) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")]
+        a, b = FisherScorer(cam, *args), FisherScorer(cam, *args)
+        a.tile_capacity = 0
+        ra, rb = a.run(w2c, H_inv=hinv), b.run(w2c, H_inv=hinv)
+        assert torch.equal(ra["scores"], rb["scores"]) and torch.equal(ra["vis_count"], rb["vis_count"])
+        # one view at a time == the batch (a view's score does not depend on its batch)
+        one = torch.cat([b.run(w2c[v:v + 1], H_inv=hinv)["scores"] for v in range(V)])
+        assert torch.equal(one, rb["scores"])
