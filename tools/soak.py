@@ -2,7 +2,8 @@
 """Randomised self-consistency soak of fr_fisher_views (no oracle: sizes the oracle cannot reach in reasonable time).
 For random scenes / image sizes / view counts the score-only launch (k_fisher_tile_v3) must agree with
 sum(cur_H * H_inv) of the out_H launch (k_fisher_tile_v3h or k_fisher_tile_v2) of the same views, the visible counts and the
-tile-instance counts of the two launches must be equal, and a second score-only launch must reproduce the first bit for bit.
+tile-instance counts of the two launches must be equal, a second score-only launch must reproduce the first bit for bit, and
+so must a scorer on packed key lists (the default keeps fixed key segments).
 usage: tools/soak.py [rounds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,15 +40,19 @@ for r in range(rounds):
     a = sc.run(w2c, out_H=cur, out_H_per_view=True)
     b = sc.run(w2c, H_inv=Hinv)
     b2 = sc.run(w2c, H_inv=Hinv)
+    pk = FisherScorer(cam, act["means3D"], act["rgb_colors"], act["rotations"], act["opacities"], act["scales"], columns=C)
+    pk.tile_capacity = 0                                     # packed key lists (scan + scatter kernel): bit-identical scores
+    bp = pk.run(w2c, H_inv=Hinv)
     want = (cur.double() * Hinv.double()[None]).sum(dim=(1, 2))
     got = b["scores"].double()
     denom = want.abs().clamp_min(1e-30)
     rel = float(((got - want).abs() / denom)[want.abs() > 1e-12].max()) if bool((want.abs() > 1e-12).any()) else 0.0
     ok = (torch.equal(a["vis_count"], b["vis_count"]) and torch.equal(a["num_rendered"], b["num_rendered"])
-          and torch.equal(b["scores"], b2["scores"]) and rel < 3e-4 and bool(torch.isfinite(got).all()))
+          and torch.equal(b["scores"], b2["scores"]) and torch.equal(b["scores"], bp["scores"]) and rel < 3e-4
+          and bool(torch.isfinite(got).all()))
     worst = max(worst, rel)
-    print(f"round {r:2d}: P={P:7d} V={V:2d} {W:3d}x{H:3d} C={C:2d}  rel err {rel:.2e}  max list {int(b['status'][2]) if 'status' in b else -1:6d}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"round {r:2d}: P={P:7d} V={V:2d} {W:3d}x{H:3d} C={C:2d}  rel err {rel:.2e}  segments {sc.tile_capacity:6d}  {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
-    del sc, cur
+    del sc, pk, cur
 print(f"soak ok: {rounds} rounds, worst relative difference {worst:.2e}")
