@@ -3923,6 +3923,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 				mask &= mask - 1ull;
 				float h0, h1, h2, h3; bool con;
 				const bool kill = pair(ent_lds + (uint32_t)j * (FR_ENT_F4 * 16), h0, h1, h2, h3, con);
+				FR_ABL(if (f.debug_mode != 29))                 // 29: ... and without the LDS atomics
 				if (con)
 				{
 					atomicAdd(&acc[0][j], (double)h0); atomicAdd(&acc[1][j], (double)h1);
@@ -3942,6 +3943,7 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 				const int e = flat >> 2, c = flat & 3;
 				const uint32_t id_e = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)real_id);
 				const float a = ((uint32_t)e < m) ? (float)acc[c][e] * dL2 : 0.f;
+				FR_ABL(if (f.debug_mode != 28))                 // 28 (tools/fe_ablate.py --outh): the walk without its global atomics
 				if (a != 0.f) atomicAdd(dst + (size_t)id_e * 4 + c, a);
 			}
 			__builtin_amdgcn_wave_barrier();

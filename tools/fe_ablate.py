@@ -38,6 +38,21 @@ def child(mode):
     sc = FisherScorer(cam, *(act[k].to(dev) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")))
     w2c = synthetic.invert_rigid(synthetic.candidate_poses(V, 2)).to(dev)
     Hi = torch.rand((P, 4), generator=torch.Generator().manual_seed(1)).to(dev)
+    if "--outh" in sys.argv:
+        # the out_H launch of 16 keyframes (k_fisher_tile_v3h): 0 = everything, 28 = no global atomics, 29 = no LDS atomics either
+        kf = synthetic.invert_rigid(synthetic.candidate_poses(16, 102)).to(dev)
+        Ht = torch.zeros((P, 4), device=dev)
+        for _ in range(3):
+            sc.launch(kf, out_H=Ht)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            sc.launch(kf, out_H=Ht)
+        e1.record()
+        torch.cuda.synchronize()
+        print("mode", mode, "H_train of 16 keyframes %.3f ms per launch" % (e0.elapsed_time(e1) / 10), flush=True)
+        return
     for _ in range(3):
         r = sc.launch(w2c, H_inv=Hi)
     torch.cuda.synchronize()
@@ -55,7 +70,8 @@ if __name__ == "__main__":
         child(int(sys.argv[2]))
     else:
         build()
-        modes = [int(a) for a in sys.argv[1:]] or [30, 31, 32, 33, 34, 35, 36, 37]
+        outh = ["--outh"] if "--outh" in sys.argv else []
+        modes = [int(a) for a in sys.argv[1:] if a != "--outh"] or ([0, 28, 29] if outh else [30, 31, 32, 33, 34, 35, 36, 37])
         for m in modes:
             env = dict(os.environ, FR_DEBUG_MODE=str(m), FISHER_RAST_SO=SO)
-            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", str(m)], env=env)
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", str(m)] + outh, env=env)
