@@ -5364,17 +5364,21 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	FrJoinGuard joins(s);
 	if (multi)
 	{
+		// compact records: written once, in place, by k_preprocess_views_c (FR_DEBUG_MODE=20 keeps the parking form for A/B runs)
+		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
+		if (!once) p.tile_cap = 0;                       // fixed key segments are filled by k_preprocess_views_c only
+		// (fixed segments keep a second [VC][T] array in LDS, the cursors: fewer views per workgroup where that would pass 64 KiB)
+		auto lds_c_of = [&](int vc) { return ((size_t)vc * p.T * (p.tile_cap ? 2 : 1) + (size_t)FR_THREADS * (vc + 1) + 12 * (size_t)vc + 13 * (size_t)FR_THREADS) * 4; };
+		while (once && p.tile_cap && p.VC > 1 && lds_c_of(p.VC) > 65536) p.VC >>= 1;
+		if (once && p.tile_cap && lds_c_of(p.VC) > 65536) p.tile_cap = 0;
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 2 * (size_t)p.VC * 8 * (size_t)p.G) * 4;
 		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 6 };
 		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
-		// compact records: written once, in place, by k_preprocess_views_c (FR_DEBUG_MODE=20 keeps the parking form for A/B runs)
-		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
-		if (!once) p.tile_cap = 0;                       // fixed key segments are filled by k_preprocess_views_c only
 		const bool dk = p.tile_cap != 0;
-		const size_t lds_c = ((size_t)p.VC * p.T * (dk ? 2 : 1) + (size_t)FR_THREADS * (p.VC + 1) + 12 * (size_t)p.VC + 13 * (size_t)FR_THREADS) * 4;
+		const size_t lds_c = lds_c_of(p.VC);
 		if (once && plan->general && plan->columns == 4 && dk) hipLaunchKernelGGL((k_preprocess_views_c<4, 2, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (once && plan->general && plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views_c<4, 2, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (once && plan->general && dk) hipLaunchKernelGGL((k_preprocess_views_c<11, 2, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);

@@ -140,3 +140,24 @@ def test_views_that_do_not_fill_the_xcds_and_tiny_maps(gpu):
         # one view at a time == the batch (a view's score does not depend on its batch)
         one = torch.cat([b.run(w2c[v:v + 1], H_inv=hinv)["scores"] for v in range(V)])
         assert torch.equal(one, rb["scores"])
+
+
+def test_an_image_of_4032_tiles_keeps_fixed_segments_within_the_lds(gpu):
+    """64 x 63 tiles: the projection kernel's per-(view, tile) histogram AND its cursors must fit the LDS a launch may ask for --
+    the library takes fewer views per workgroup there; scores equal those of the packed-list path, no overflow."""
+    from fisher_rast import synthetic
+    from fisher_rast.ops import FisherScorer
+    from models.SLAM.utils.recon_helpers import setup_camera
+    P, V, W, H = 30_000, 8, 1024, 1008
+    act = synthetic.activate(synthetic.room_shell(P, seed=13))
+    w2c = synthetic.invert_rigid(synthetic.candidate_poses(V, seed=13)).to(gpu)
+    cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=gpu)
+    hinv = (torch.rand((P, 4), generator=torch.Generator().manual_seed(8)) + 0.05).to(gpu)
+    args = [act[k].to(gpu) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")]
+    a, b = FisherScorer(cam, *args), FisherScorer(cam, *args)
+    a.tile_capacity = 0
+    b.tile_capacity = 2048                                   # 4032 tiles x 2048 keys x 8 B = 63 MiB per view
+    ra, rb = a.run(w2c, H_inv=hinv), b.run(w2c, H_inv=hinv)
+    assert b.tile_capacity == 2048
+    assert torch.equal(ra["scores"], rb["scores"]) and float(ra["scores"].min()) > 0
+    assert torch.equal(ra["vis_count"], rb["vis_count"])
