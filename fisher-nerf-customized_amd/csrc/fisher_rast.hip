@@ -4090,6 +4090,38 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFi
 	fr_strip_pass<16, 4, NQ, decltype(pass2), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done, pass2);
 }
 
+// fr_fisher_cfg.poses_are_c2w: the caller hands camera-to-world poses (what pose_eval receives, gaussian.py:1354-1362) and the
+// library inverts them -- one thread per pose, cofactor expansion in double, rounded once to float -- instead of a dozen
+// rocSOLVER / elementwise launches of torch.linalg.inv on 64 4x4 matrices.
+__global__ __launch_bounds__(64) void k_invert_poses(int n, const float* __restrict__ m_in, float* __restrict__ m_out)
+{
+	const int i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) return;
+	double m[16], inv[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) m[k] = (double)m_in[16 * (size_t)i + k];
+	inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+	inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+	inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+	inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+	inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+	inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+	inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+	inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+	inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+	inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+	inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+	inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+	inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+	inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+	inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+	inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+	const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+	const double r = 1.0 / det;                       // (a singular pose gives inf / nan, as torch.linalg.inv raises: the scores then show it)
+#pragma unroll
+	for (int k = 0; k < 16; k++) m_out[16 * (size_t)i + k] = (float)(inv[k] * r);
+}
+
 __global__ __launch_bounds__(FR_THREADS) void k_reduce_scores(const float* __restrict__ tile_scores, int T,
                                                               const int* __restrict__ status, int n_groups, float* __restrict__ out_scores,
                                                               int* __restrict__ status_out)
@@ -5759,7 +5791,7 @@ static int fr_debug_mode()
 
 #define FR_MAX_GROUPS 4              // view groups of one fr_fisher_views call (fr_pick_groups)
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, w2c_inv, status, keys, fallback, total;
 	size_t PV;                   // slots per view of the compact records: projection workgroups * 256 G (>= P)
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
@@ -5790,6 +5822,7 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.tile_off = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.tile_fill = o; o = fr_align(o + (size_t)(V * T) * 4);
 	L.tile_scores = o; o = fr_align(o + (size_t)(V * T) * 4);
+	L.w2c_inv = o; o = fr_align(o + (size_t)V * 64);
 	L.status = o; o = fr_align(o + 64);
 	const size_t R = (size_t)(max_rendered > 0 ? max_rendered : 1);
 	L.keys = o; o = fr_align(o + R * 8);
@@ -5940,6 +5973,13 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	FrParams p;
 	fr_fill_params(p, cfg, g, V);
 	p.w2c = fc->w2c;
+	if (fc->poses_are_c2w)
+	{
+		float* inv = (float*)(ws + L.w2c_inv);
+		hipLaunchKernelGGL(k_invert_poses, dim3((V + 63) / 64), dim3(64), 0, s, V, fc->w2c, inv);
+		if ((rc = fr_check_launch("k_invert_poses"))) return rc;
+		p.w2c = inv;
+	}
 	p.radii = (int*)(ws + L.radii);
 	p.vis_list = (FrVisEntry*)(ws + L.radii);
 	p.vis_n = (uint32_t*)(ws + L.vis_n);

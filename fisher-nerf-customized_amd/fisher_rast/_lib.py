@@ -61,6 +61,7 @@ class FisherCfg(ctypes.Structure):
         ("dL_dpix_image", _f32p),
         ("dL_image_view_stride", ctypes.c_int64),
         ("tile_capacity", ctypes.c_int32),
+        ("poses_are_c2w", ctypes.c_int32),
     ]
 
 

@@ -308,8 +308,9 @@ class FisherScorer:
             ws = self._ws[slot] = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
         return ws
 
-    def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None):
-        """Enqueue one batch (no sync).  w2c: [V,4,4] world->camera on the device.
+    def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None, poses_are_c2w=False):
+        """Enqueue one batch (no sync).  w2c: [V,4,4] world->camera on the device (camera->world with `poses_are_c2w`: the
+        library inverts them).
         Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4].
 
         The batch is cut into `self.n_streams` groups of views that run on separate HIP streams with separate
@@ -359,6 +360,7 @@ class FisherScorer:
                 ws = self._workspace(Vg, max_rendered, gi)
                 fc = FisherCfg()
                 fc.n_views, fc.columns, fc.dL_dpix = Vg, C, self.dL
+                fc.poses_are_c2w = 1 if poses_are_c2w else 0
                 fc.tile_capacity = self.tile_capacity if Vg * self.tiles * self.tile_capacity < (1 << 32) else 0
                 fc.w2c = ctypes.c_void_p(w2c.data_ptr() + v0 * 64)
                 if H_inv is not None:

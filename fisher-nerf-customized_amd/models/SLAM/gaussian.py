@@ -186,21 +186,21 @@ class FisherOps:
         the two 16-byte status words travel to the host together with the scores."""
         extra = random_gaussian_params if self.FISHER_COLUMNS == 11 else None
         c2w = self._stack_poses(poses)
-        w2c = torch.linalg.inv(c2w)
         scorer = self._scorer(extra)
         V, K = int(c2w.shape[0]), len(self.keyframe_list)
         if 0 < K and max(V, K) <= scorer.max_views_per_launch():
             kf = self._stack_poses([kf['est_w2c'] for kf in self.keyframe_list])
             H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
             r1 = scorer.launch(kf, out_H=H_train)
-            r2 = scorer.launch(w2c, H_inv=torch.reciprocal(H_train + self.H_TRAIN_REG))
+            # (the poses go in as they are: the library inverts them -- one kernel in place of torch.linalg.inv's dozen launches)
+            r2 = scorer.launch(c2w, H_inv=torch.reciprocal(H_train + self.H_TRAIN_REG), poses_are_c2w=True)
             host = torch.cat([r1["status"], r2["status"], r2["scores"].view(torch.int32)]).cpu()      # the one sync
             if int(host[1]) == 0 and int(host[5]) == 0:
                 return host[8:].view(torch.float32).clone(), c2w
             # the tile-instance buffer was too small (nothing was accumulated or scored): the growing path below repeats both
         H_train = self.compute_H_train(extra)
         H_train_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
-        res = scorer.run(w2c, H_inv=H_train_inv)
+        res = scorer.run(torch.linalg.inv(c2w), H_inv=H_train_inv)
         scores = res["scores"].cpu()
         return scores, c2w
 

@@ -178,6 +178,7 @@ typedef struct fr_fisher_cfg {
 	                               > 0: every (view, tile) owns a fixed segment of tile_capacity keys, which the projection kernel
 	                               fills itself -- no scan dependency and no scatter kernel; needs n_views * tiles * tile_capacity
 	                               <= max_rendered (and < 2^32).  A tile with more instances than that: overflow, status[3] = 1. */
+	int32_t poses_are_c2w;      /* 1: `w2c` holds camera-to-world poses; the library inverts them (one small kernel) */
 } fr_fisher_cfg;
 
 size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);

@@ -161,3 +161,18 @@ def test_an_image_of_4032_tiles_keeps_fixed_segments_within_the_lds(gpu):
     assert b.tile_capacity == 2048
     assert torch.equal(ra["scores"], rb["scores"]) and float(ra["scores"].min()) > 0
     assert torch.equal(ra["vis_count"], rb["vis_count"])
+
+
+def test_camera_to_world_poses_are_inverted_by_the_library(scene, gpu):
+    """fr_fisher_cfg.poses_are_c2w: the same scores as with torch.linalg.inv on the host side (the inverse is taken in double
+    and rounded once; torch's LU runs in float), for rigid poses and for a sheared, scaled one."""
+    s = scene
+    hinv = s["H_inv"][:, :4].contiguous()
+    sc = _scorer(s, gpu, 4, 16384)
+    w2c = s["w2c"].clone()
+    w2c[3, :3, :3] = w2c[3, :3, :3] @ torch.tensor([[1.02, 0.03, 0.0], [0.0, 0.97, 0.01], [0.0, 0.0, 1.0]], device=gpu)
+    c2w = torch.linalg.inv(w2c.double()).float()
+    want = sc.run(torch.linalg.inv(c2w.double()).float(), H_inv=hinv)["scores"]
+    got = sc.launch(c2w, H_inv=hinv, poses_are_c2w=True)
+    assert int(got["status"].cpu()[1]) == 0
+    assert rel_err(got["scores"].cpu().numpy(), want.cpu().numpy()) < 2e-5
