@@ -183,7 +183,8 @@ typedef struct fr_fisher_cfg {
 
 size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);
 /* Byte offsets of the named sections inside the scorer's workspace (for tests / debuggers):
- * [0] tile_count u32[V,T], [1] tile_offset u32[V,T], [2] keys u64[R] (sorted per (view, tile): (depth_bits << 32) | gaussian_index),
+ * [0] tile_count u32[V,T], [1] tile_offset u32[V,T], [2] keys u64[R] (sorted per (view, tile) from tile_offset on: (depth_bits << 32) |
+ *     record slot with packed lists, (depth_bits << 32) | slot << 4 | strips of the tile reached with fixed segments -- tile_capacity),
  * [3] per-(view, Gaussian) 32-byte records [V,P] (valid where visible), [4] per-(view, Gaussian) 64-byte scorer records [V,P],
  * [5] tile_scores f32[V,T], [6] status i32[4], [7] visible-list lengths u32[V, blocks] */
 int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns,
