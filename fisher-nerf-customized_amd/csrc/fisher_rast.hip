@@ -971,14 +971,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			for (int vv = 0; vv < nv; vv++)
 			{
 				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, s_wm + 12 * vv) : pw;
-				const fr_f3 p_view = fr_xform4x3(po, vm);
+				const fr_f3 p_view = fr_xform4x3(po, vm);        // (the near-plane decision: the reference's arithmetic, unfused)
 				bool keep = live && !(p_view.z <= 0.001f);
 				if (early)
 				{
-					// (a bound, not the projection: v_rcp_f32 / v_sqrt_f32 are a few 1e-7 off, the slack below is 1e-3 and two pixels)
-					const fr_f4 ph = fr_xform4x4(po, pm);
-					const float p_w = __builtin_amdgcn_rcpf(ph.w + 0.0000001f);
-					const float px = ((ph.x * p_w + 1.0f) * (float)p.W - 1.0f) * 0.5f, py = ((ph.y * p_w + 1.0f) * (float)p.H - 1.0f) * 0.5f;
+					// (a bound, not the projection: fused multiply-adds, v_rcp_f32 / v_sqrt_f32 -- a few 1e-7 off; the slack below is
+					// 1e-3 and two pixels)
+#pragma clang fp contract(fast)
+					const float hx = __builtin_fmaf(pm[8], po.z, __builtin_fmaf(pm[4], po.y, __builtin_fmaf(pm[0], po.x, pm[12])));
+					const float hy = __builtin_fmaf(pm[9], po.z, __builtin_fmaf(pm[5], po.y, __builtin_fmaf(pm[1], po.x, pm[13])));
+					const float hw = __builtin_fmaf(pm[11], po.z, __builtin_fmaf(pm[7], po.y, __builtin_fmaf(pm[3], po.x, pm[15])));
+					const float p_w = __builtin_amdgcn_rcpf(hw + 0.0000001f);
+					const float px = ((hx * p_w + 1.0f) * (float)p.W - 1.0f) * 0.5f, py = ((hy * p_w + 1.0f) * (float)p.H - 1.0f) * 0.5f;
 					const float iz = __builtin_amdgcn_rcpf(p_view.z);
 					const float jx = fminf(fabsf(p_view.x * iz) * 1.001f, lx), jy = fminf(fabsf(p_view.y * iz) * 1.001f, ly);
 					const float kc = fx2 * (1.0f + jx * jx) + fy2 * (1.0f + jy * jy);

@@ -152,6 +152,16 @@ FR_HD void fr_cov3d(fr_f3 scale, float mod, fr_f4 rot, float* cov3D)
 #undef FR_SIG
 }
 
+// FR_CONTRACT (first statement of a function body or block): the expressions below it may be fused into multiply-adds.  Used on
+// the scorer's records only (the FAST instantiation of fr_cov2d_setup, fr_scorer_poly_g), whose bar is 1e-4 on the scores: never by
+// the forward projection, whose radii / rectangles / depths are compared bit for bit, and not by the gradient chains either --
+// fused, the rotation gradient of an isotropic Gaussian stops cancelling to the exact 0 the reference's arithmetic gives.
+#if defined(__clang__)
+#define FR_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define FR_CONTRACT
+#endif
+
 // Division policy of the Jacobian helpers: IEEE `/` by default (the single-view rasteriser and the host harness); the
 // Fisher scorer, whose bar is 1e-4 on the scores, instantiates them with FAST = true: one v_rcp_f32 (1 ulp) + multiply.
 template <bool FAST> FR_HD float fr_divt(float a, float b)
@@ -172,44 +182,47 @@ struct fr_cov2d {
 	float cov00, cov01, cov11; // before the +0.3 low-pass
 };
 
+// (one body, two instantiations: FAST = false is the forward projection's -- exact, unfused --, FAST = true the scorer's)
+#define FR_COV2D_SETUP_BODY \
+	fr_f3 t = fr_xform4x3(mean, view);\
+	const float limx = 1.3f * tan_fovx;\
+	const float limy = 1.3f * tan_fovy;\
+	c.txtz = fr_divt<FAST>(t.x, t.z);\
+	c.tytz = fr_divt<FAST>(t.y, t.z);\
+	t.x = fminf(limx, fmaxf(-limx, c.txtz)) * t.z;\
+	t.y = fminf(limy, fmaxf(-limy, c.tytz)) * t.z;\
+	c.tx = t.x; c.ty = t.y; c.tz = t.z;\
+	const float J00 = fr_divt<FAST>(focal_x, t.z);\
+	const float J02 = fr_divt<FAST>(-(focal_x * t.x), (t.z * t.z));\
+	const float J11 = fr_divt<FAST>(focal_y, t.z);\
+	const float J12 = fr_divt<FAST>(-(focal_y * t.y), (t.z * t.z));\
+	for (int cc = 0; cc < 3; cc++)\
+		for (int r = 0; r < 3; r++)\
+			c.Wc[cc][r] = view[cc + 4 * r];\
+	for (int r = 0; r < 3; r++)\
+	{\
+		c.T0[r] = c.Wc[0][r] * J00 + c.Wc[2][r] * J02;\
+		c.T1[r] = c.Wc[1][r] * J11 + c.Wc[2][r] * J12;\
+	}\
+	for (int i = 0; i < 6; i++) c.c3[i] = cov3D[i];\
+	const float c0 = cov3D[0], c1 = cov3D[1], c2 = cov3D[2], c3 = cov3D[3], c4 = cov3D[4], c5 = cov3D[5];\
+	const float A00 = (c.T0[0] * c0 + c.T0[1] * c1) + c.T0[2] * c2;\
+	const float A10 = (c.T0[0] * c1 + c.T0[1] * c3) + c.T0[2] * c4;\
+	const float A20 = (c.T0[0] * c2 + c.T0[1] * c4) + c.T0[2] * c5;\
+	const float A01 = (c.T1[0] * c0 + c.T1[1] * c1) + c.T1[2] * c2;\
+	const float A11 = (c.T1[0] * c1 + c.T1[1] * c3) + c.T1[2] * c4;\
+	const float A21 = (c.T1[0] * c2 + c.T1[1] * c4) + c.T1[2] * c5;\
+	c.cov00 = (A00 * c.T0[0] + A10 * c.T0[1]) + A20 * c.T0[2];\
+	c.cov01 = (A01 * c.T0[0] + A11 * c.T0[1]) + A21 * c.T0[2];\
+	c.cov11 = (A01 * c.T1[0] + A11 * c.T1[1]) + A21 * c.T1[2];
 template <bool FAST = false>
 FR_HD void fr_cov2d_setup(fr_f3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
                           const float* cov3D, const float* view, fr_cov2d& c)
 {
-	fr_f3 t = fr_xform4x3(mean, view);
-	const float limx = 1.3f * tan_fovx;
-	const float limy = 1.3f * tan_fovy;
-	c.txtz = fr_divt<FAST>(t.x, t.z);
-	c.tytz = fr_divt<FAST>(t.y, t.z);
-	t.x = fminf(limx, fmaxf(-limx, c.txtz)) * t.z;
-	t.y = fminf(limy, fmaxf(-limy, c.tytz)) * t.z;
-	c.tx = t.x; c.ty = t.y; c.tz = t.z;
-	const float J00 = fr_divt<FAST>(focal_x, t.z);
-	const float J02 = fr_divt<FAST>(-(focal_x * t.x), (t.z * t.z));
-	const float J11 = fr_divt<FAST>(focal_y, t.z);
-	const float J12 = fr_divt<FAST>(-(focal_y * t.y), (t.z * t.z));
-	for (int cc = 0; cc < 3; cc++)
-		for (int r = 0; r < 3; r++)
-			c.Wc[cc][r] = view[cc + 4 * r];
-	for (int r = 0; r < 3; r++)
-	{
-		// T[0][r] = W[0][r]*J00 + W[1][r]*0 + W[2][r]*J02 ; T[1][r] = W[0][r]*0 + W[1][r]*J11 + W[2][r]*J12
-		c.T0[r] = c.Wc[0][r] * J00 + c.Wc[2][r] * J02;
-		c.T1[r] = c.Wc[1][r] * J11 + c.Wc[2][r] * J12;
-	}
-	for (int i = 0; i < 6; i++) c.c3[i] = cov3D[i];
-	const float c0 = cov3D[0], c1 = cov3D[1], c2 = cov3D[2], c3 = cov3D[3], c4 = cov3D[4], c5 = cov3D[5];
-	// A[k][r] = T[r][0]*Vrk[0][k] + T[r][1]*Vrk[1][k] + T[r][2]*Vrk[2][k]
-	const float A00 = (c.T0[0] * c0 + c.T0[1] * c1) + c.T0[2] * c2;
-	const float A10 = (c.T0[0] * c1 + c.T0[1] * c3) + c.T0[2] * c4;
-	const float A20 = (c.T0[0] * c2 + c.T0[1] * c4) + c.T0[2] * c5;
-	const float A01 = (c.T1[0] * c0 + c.T1[1] * c1) + c.T1[2] * c2;
-	const float A11 = (c.T1[0] * c1 + c.T1[1] * c3) + c.T1[2] * c4;
-	const float A21 = (c.T1[0] * c2 + c.T1[1] * c4) + c.T1[2] * c5;
-	c.cov00 = (A00 * c.T0[0] + A10 * c.T0[1]) + A20 * c.T0[2];
-	c.cov01 = (A01 * c.T0[0] + A11 * c.T0[1]) + A21 * c.T0[2];
-	c.cov11 = (A01 * c.T1[0] + A11 * c.T1[1]) + A21 * c.T1[2];
+	if constexpr (FAST) { FR_CONTRACT FR_COV2D_SETUP_BODY }
+	else { FR_COV2D_SETUP_BODY }
 }
+#undef FR_COV2D_SETUP_BODY
 
 // ---- forward.cu:181-255: everything preprocessCUDA derives for one Gaussian -------------------------
 struct fr_splat {
@@ -562,6 +575,7 @@ FR_HD void fr_mean_rows_g(fr_f3 mean, const float* cov3D, const float* view, con
 template <int C>
 FR_HD void fr_scorer_poly_g(const float Rg[3][5], const float (*Cg)[3], const float* hv, float q[12])
 {
+	FR_CONTRACT
 	// upper triangle of Q = sum_c hv[c] R_c^T R_c, off-diagonal entries doubled: (i, j) at 0 1 2 3 4 / 5 6 7 8 / 9 10 11 / 12 13 / 14
 	float qf[15];
 	int n = 0;
