@@ -353,57 +353,59 @@ FR_HD fr_f3 fr_sh_to_rgb(int deg, fr_f3 pos, fr_f3 campos, const float* sh, uint
 
 // backward.cu:347-407, second half of computeCov2DCUDARelocated: (dL_da, dL_db, dL_dc) -- the gradient w.r.t. the three
 // entries of cov2D -- -> dL_dcov3D[6] and the covariance part of dL_dmean.  `nonzero`: the reference's `denom2inv != 0` branch.
+#define FR_ABC_BACKWARD_BODY \
+	const float limx = 1.3f * tan_fovx; \
+	const float limy = 1.3f * tan_fovy; \
+	const float x_grad_mul = (c.txtz < -limx || c.txtz > limx) ? 0.f : 1.f; \
+	const float y_grad_mul = (c.tytz < -limy || c.tytz > limy) ? 0.f : 1.f; \
+	const float* T0 = c.T0; const float* T1 = c.T1; \
+	if (nonzero) \
+	{ \
+		dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc); \
+		dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc); \
+		dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc); \
+		dcov[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc; \
+		dcov[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc; \
+		dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc; \
+	} \
+	else \
+	{ \
+		for (int i = 0; i < 6; i++) dcov[i] = 0; \
+	} \
+	const float c0 = c.c3[0], c1 = c.c3[1], c2 = c.c3[2], c3 = c.c3[3], c4 = c.c3[4], c5 = c.c3[5]; \
+	const float t0v0 = T0[0] * c0 + T0[1] * c1 + T0[2] * c2; \
+	const float t0v1 = T0[0] * c1 + T0[1] * c3 + T0[2] * c4; \
+	const float t0v2 = T0[0] * c2 + T0[1] * c4 + T0[2] * c5; \
+	const float t1v0 = T1[0] * c0 + T1[1] * c1 + T1[2] * c2; \
+	const float t1v1 = T1[0] * c1 + T1[1] * c3 + T1[2] * c4; \
+	const float t1v2 = T1[0] * c2 + T1[1] * c4 + T1[2] * c5; \
+	const float dL_dT00 = 2 * t0v0 * dL_da + t1v0 * dL_db; \
+	const float dL_dT01 = 2 * t0v1 * dL_da + t1v1 * dL_db; \
+	const float dL_dT02 = 2 * t0v2 * dL_da + t1v2 * dL_db; \
+	const float dL_dT10 = 2 * t1v0 * dL_dc + t0v0 * dL_db; \
+	const float dL_dT11 = 2 * t1v1 * dL_dc + t0v1 * dL_db; \
+	const float dL_dT12 = 2 * t1v2 * dL_dc + t0v2 * dL_db; \
+	const float dL_dJ00 = c.Wc[0][0] * dL_dT00 + c.Wc[0][1] * dL_dT01 + c.Wc[0][2] * dL_dT02; \
+	const float dL_dJ02 = c.Wc[2][0] * dL_dT00 + c.Wc[2][1] * dL_dT01 + c.Wc[2][2] * dL_dT02; \
+	const float dL_dJ11 = c.Wc[1][0] * dL_dT10 + c.Wc[1][1] * dL_dT11 + c.Wc[1][2] * dL_dT12; \
+	const float dL_dJ12 = c.Wc[2][0] * dL_dT10 + c.Wc[2][1] * dL_dT11 + c.Wc[2][2] * dL_dT12; \
+	const float tz = fr_divt<FAST>(1.f, c.tz); \
+	const float tz2 = tz * tz; \
+	const float tz3 = tz2 * tz; \
+	const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02; \
+	const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12; \
+	const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c.tx) * tz3 * dL_dJ02 + (2 * h_y * c.ty) * tz3 * dL_dJ12; \
+	dmean.x = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz; \
+	dmean.y = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz; \
+	dmean.z = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
 template <bool FAST = false>
 FR_HD void fr_cov2d_abc_backward(const fr_cov2d& c, float h_x, float h_y, float tan_fovx, float tan_fovy,
                                  const float* view, float dL_da, float dL_db, float dL_dc, bool nonzero, fr_f3& dmean, float* dcov)
 {
-	const float limx = 1.3f * tan_fovx;
-	const float limy = 1.3f * tan_fovy;
-	const float x_grad_mul = (c.txtz < -limx || c.txtz > limx) ? 0.f : 1.f;
-	const float y_grad_mul = (c.tytz < -limy || c.tytz > limy) ? 0.f : 1.f;
-	const float* T0 = c.T0; const float* T1 = c.T1;
-	if (nonzero)
-	{
-		dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
-		dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
-		dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
-		dcov[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
-		dcov[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
-		dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
-	}
-	else
-	{
-		for (int i = 0; i < 6; i++) dcov[i] = 0;
-	}
-	// Vrk columns: V[0] = (c0,c1,c2), V[1] = (c1,c3,c4), V[2] = (c2,c4,c5)
-	const float c0 = c.c3[0], c1 = c.c3[1], c2 = c.c3[2], c3 = c.c3[3], c4 = c.c3[4], c5 = c.c3[5];
-	const float t0v0 = T0[0] * c0 + T0[1] * c1 + T0[2] * c2;
-	const float t0v1 = T0[0] * c1 + T0[1] * c3 + T0[2] * c4;
-	const float t0v2 = T0[0] * c2 + T0[1] * c4 + T0[2] * c5;
-	const float t1v0 = T1[0] * c0 + T1[1] * c1 + T1[2] * c2;
-	const float t1v1 = T1[0] * c1 + T1[1] * c3 + T1[2] * c4;
-	const float t1v2 = T1[0] * c2 + T1[1] * c4 + T1[2] * c5;
-	const float dL_dT00 = 2 * t0v0 * dL_da + t1v0 * dL_db;
-	const float dL_dT01 = 2 * t0v1 * dL_da + t1v1 * dL_db;
-	const float dL_dT02 = 2 * t0v2 * dL_da + t1v2 * dL_db;
-	const float dL_dT10 = 2 * t1v0 * dL_dc + t0v0 * dL_db;
-	const float dL_dT11 = 2 * t1v1 * dL_dc + t0v1 * dL_db;
-	const float dL_dT12 = 2 * t1v2 * dL_dc + t0v2 * dL_db;
-	const float dL_dJ00 = c.Wc[0][0] * dL_dT00 + c.Wc[0][1] * dL_dT01 + c.Wc[0][2] * dL_dT02;
-	const float dL_dJ02 = c.Wc[2][0] * dL_dT00 + c.Wc[2][1] * dL_dT01 + c.Wc[2][2] * dL_dT02;
-	const float dL_dJ11 = c.Wc[1][0] * dL_dT10 + c.Wc[1][1] * dL_dT11 + c.Wc[1][2] * dL_dT12;
-	const float dL_dJ12 = c.Wc[2][0] * dL_dT10 + c.Wc[2][1] * dL_dT11 + c.Wc[2][2] * dL_dT12;
-	const float tz = fr_divt<FAST>(1.f, c.tz);
-	const float tz2 = tz * tz;
-	const float tz3 = tz2 * tz;
-	const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-	const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-	const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c.tx) * tz3 * dL_dJ02 + (2 * h_y * c.ty) * tz3 * dL_dJ12;
-	// transformVec4x3Transpose
-	dmean.x = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;
-	dmean.y = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
-	dmean.z = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+	if constexpr (FAST) { FR_CONTRACT FR_ABC_BACKWARD_BODY }
+	else { FR_ABC_BACKWARD_BODY }
 }
+#undef FR_ABC_BACKWARD_BODY
 
 // backward.cu:335-407: (dL_dconic.x,.y,.w) -> dL_dcov3D[6] and the covariance part of dL_dmean
 template <bool FAST = false>
@@ -424,17 +426,21 @@ FR_HD void fr_cov2d_backward(const fr_cov2d& c, float h_x, float h_y, float tan_
 }
 
 // backward.cu:557-574: dL_dmean3D += Mp * (dL_dmean2D.x, dL_dmean2D.y); returns Mp as 3 rows of 2
+#define FR_PROJ_JACOBIAN_BODY \
+	fr_f4 m_hom = fr_xform4x4(m, proj); \
+	float m_w = fr_divt<FAST>(1.0f, m_hom.w + 0.0000001f); \
+	float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w; \
+	float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w; \
+	Mp[0][0] = (proj[0] * m_w - proj[3] * mul1); Mp[0][1] = (proj[1] * m_w - proj[3] * mul2); \
+	Mp[1][0] = (proj[4] * m_w - proj[7] * mul1); Mp[1][1] = (proj[5] * m_w - proj[7] * mul2); \
+	Mp[2][0] = (proj[8] * m_w - proj[11] * mul1); Mp[2][1] = (proj[9] * m_w - proj[11] * mul2);
 template <bool FAST = false>
 FR_HD void fr_proj_jacobian(fr_f3 m, const float* proj, float Mp[3][2])
 {
-	fr_f4 m_hom = fr_xform4x4(m, proj);
-	float m_w = fr_divt<FAST>(1.0f, m_hom.w + 0.0000001f);
-	float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
-	float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
-	Mp[0][0] = (proj[0] * m_w - proj[3] * mul1); Mp[0][1] = (proj[1] * m_w - proj[3] * mul2);
-	Mp[1][0] = (proj[4] * m_w - proj[7] * mul1); Mp[1][1] = (proj[5] * m_w - proj[7] * mul2);
-	Mp[2][0] = (proj[8] * m_w - proj[11] * mul1); Mp[2][1] = (proj[9] * m_w - proj[11] * mul2);
+	if constexpr (FAST) { FR_CONTRACT FR_PROJ_JACOBIAN_BODY }
+	else { FR_PROJ_JACOBIAN_BODY }
 }
+#undef FR_PROJ_JACOBIAN_BODY
 
 // backward.cu:412-475: dL_dcov3D[6] -> dL_dscale, dL_drot
 FR_HD void fr_cov3d_backward(fr_f3 scale, float mod, fr_f4 rot, const float* dcov, fr_f3& dscale, fr_f4& drot)
@@ -534,39 +540,38 @@ FR_HD void fr_scale_rot_jacobian(fr_f3 scale, float mod, fr_f4 rot, const float 
 
 // Rg[r] = row of camera-frame mean component r over gamma(u) = (ux, uy, ux^2, ux uy, uy^2), u = -g;
 // Bg (optional) = d(dL_dcov3D[6]) / d(dL_da, dL_db, dL_dc) for fr_scale_rot_jacobian; cov2d_out: cov2D before the +0.3.
+#define FR_MEAN_ROWS_G_BODY \
+	fr_cov2d c; \
+	fr_cov2d_setup<FAST>(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c); \
+	if (cov2d_out) { cov2d_out[0] = c.cov00; cov2d_out[1] = c.cov01; cov2d_out[2] = c.cov11; } \
+	const float a = c.cov00 + 0.3f, b = c.cov01, cc = c.cov11 + 0.3f; \
+	const float denom = a * cc - b * b; \
+	const float d2 = denom * denom; \
+	const float f = d2 < 3.0e38f ? fr_divt<FAST>(d2, d2 + 0.0000001f) : 0.f; \
+	if (f_out) *f_out = f; \
+	float Mp[3][2]; \
+	fr_proj_jacobian<FAST>(mean, proj, Mp); \
+	const float hw = (float)(0.5 * W), hh = (float)(0.5 * H); \
+	for (int k = 0; k < 3; k++) { Rg[k][0] = Mp[k][0] * hw; Rg[k][1] = Mp[k][1] * hh; } \
+	const float wj[3] = { 0.5f * f, f, 0.5f * f }; \
+	for (int j = 0; j < 3; j++) \
+	{ \
+		fr_f3 dm; float dcov[6]; \
+		fr_cov2d_abc_backward<FAST>(c, focal_x, focal_y, tan_fovx, tan_fovy, view, \
+		                            j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, true, dm, dcov); \
+		Rg[0][2 + j] = dm.x * wj[j]; Rg[1][2 + j] = dm.y * wj[j]; Rg[2][2 + j] = dm.z * wj[j]; \
+		if (Bg) \
+			for (int i = 0; i < 6; i++) Bg[i][j] = dcov[i] * wj[j]; \
+	}
 template <bool FAST = false>
 FR_HD void fr_mean_rows_g(fr_f3 mean, const float* cov3D, const float* view, const float* proj,
                           float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                           float Rg[3][5], float (*Bg)[3], float* cov2d_out, float* f_out)
 {
-	fr_cov2d c;
-	fr_cov2d_setup<FAST>(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c);
-	if (cov2d_out) { cov2d_out[0] = c.cov00; cov2d_out[1] = c.cov01; cov2d_out[2] = c.cov11; }
-	const float a = c.cov00 + 0.3f, b = c.cov01, cc = c.cov11 + 0.3f;
-	const float denom = a * cc - b * b;
-	const float d2 = denom * denom;
-	const float f = d2 < 3.0e38f ? fr_divt<FAST>(d2, d2 + 0.0000001f) : 0.f;     // denom^2 * denom2inv (backward.cu:337; 0 where denom2inv == 0)
-	if (f_out) *f_out = f;
-	float Mp[3][2];
-	fr_proj_jacobian<FAST>(mean, proj, Mp);
-	const float hw = (float)(0.5 * W), hh = (float)(0.5 * H);
-	// dL_dmean2D = -w (W/2 gx, H/2 gy) = w (W/2 ux, H/2 uy)
-	for (int k = 0; k < 3; k++) { Rg[k][0] = Mp[k][0] * hw; Rg[k][1] = Mp[k][1] * hh; }
-	// (dL_da, dL_db, dL_dc) = w f (ux^2 / 2, ux uy, uy^2 / 2)
-	const float wj[3] = { 0.5f * f, f, 0.5f * f };
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-	for (int j = 0; j < 3; j++)
-	{
-		fr_f3 dm; float dcov[6];
-		fr_cov2d_abc_backward<FAST>(c, focal_x, focal_y, tan_fovx, tan_fovy, view,
-		                            j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, true, dm, dcov);
-		Rg[0][2 + j] = dm.x * wj[j]; Rg[1][2 + j] = dm.y * wj[j]; Rg[2][2 + j] = dm.z * wj[j];
-		if (Bg)
-			for (int i = 0; i < 6; i++) Bg[i][j] = dcov[i] * wj[j];
-	}
+	if constexpr (FAST) { FR_CONTRACT FR_MEAN_ROWS_G_BODY }
+	else { FR_MEAN_ROWS_G_BODY }
 }
+#undef FR_MEAN_ROWS_G_BODY
 
 // The 12 coefficients of F(u) = sum_c hv[c] (R_c . gamma(u))^2 as a bivariate polynomial in (ux, uy) (terms of degree 2, 3
 // and 4 only): Rg = the three mean rows, Cg = the seven scale / rotation rows over (ux^2, ux uy, uy^2) (C >= 11), hv = the
