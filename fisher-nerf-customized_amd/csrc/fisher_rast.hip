@@ -116,6 +116,7 @@ struct FrParams {
 	uint32_t tile_cap;           // 0: tile segments packed by the scan; > 0: every (view, tile) owns keys[(v T + t) tile_cap ...), filled by
 	                             // the projection kernel itself (k_preprocess_views_c<.., true>): no scan dependency, no scatter kernel
 	int legacy_sort;             // FR_DEBUG_MODE=6: the LDS-resident sort network of round 1 (A/B runs)
+	int prefiltered;             // GaussianRasterizationSettings.prefiltered (single-view API): a near-plane-culled point raises status[3]
 	int ablate;                  // -DFR_ABLATE builds only (tools/fe_ablate.py): FR_DEBUG_MODE 30..34 drop parts of the direct key scatter
 };
 #ifdef FR_ABLATE
@@ -239,6 +240,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess(FrParams p)
 		fr_f3 p_view = fr_xform4x3(po, vm);
 		fr_splat s;
 		s.radius = 0;
+		// auxiliary.h:156-160: with `prefiltered` the reference prints "Point is filtered although prefiltered is set" and traps the
+		// device; here the status word carries the fact to the host, which raises (diff_gaussian_rasterization / fisher_rast.ops)
+		if (p.prefiltered && p_view.z <= 0.001f) p.status[3] = 1;
 		if (!(p_view.z <= 0.001f))
 		{
 			float c3[6];
@@ -417,8 +421,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 			for (int w = 0; w < 16; w++) mm = wsum[w] > mm ? wsum[w] : mm;
 			status[0] = (int)carry;
 			status[1] = ((long long)carry > capacity) ? 1 : 0;
-			status[2] = (int)mm;
-			status[3] = 0;
+			status[2] = (int)mm;                   // (status[3]: zero-filled before the front end; k_preprocess raises it for `prefiltered`)
 		}
 	}
 	if (num_rendered)
@@ -5273,6 +5276,7 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 	p.focal_y = p.H / (2.0f * cfg->tanfovy);   // rasterizer_impl.cu:222-223
 	p.focal_x = p.W / (2.0f * cfg->tanfovx);
 	p.mod = cfg->scale_modifier; p.D = cfg->sh_degree; p.M = cfg->sh_coeffs;
+	p.prefiltered = cfg->prefiltered;
 	p.bg = cfg->bg; p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
 	p.means3D = g->means3D; p.colors = g->colors_precomp; p.shs = g->shs; p.opac = g->opacities;
 	p.scales = g->scales; p.rots = g->rotations;
@@ -5976,6 +5980,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	char* ws = (char*)workspace;
 	FrParams p;
 	fr_fill_params(p, cfg, g, V);
+	p.prefiltered = 0;            // (candidate views cull by design; status[3] means something else here)
 	p.w2c = fc->w2c;
 	if (fc->poses_are_c2w)
 	{

@@ -138,6 +138,9 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
             # same host synchronisation as the reference (rasterizer_impl.cu:282: cudaMemcpy of num_rendered)
             st = status.cpu()
             num_rendered = int(st[0])
+            if int(st[3]):
+                # auxiliary.h:156-160 prints this and traps the device; here the call fails and the device stays usable
+                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
             if int(st[1]) == 0:
                 break
             capacity = int(num_rendered * 1.25) + 1024

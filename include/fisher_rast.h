@@ -69,7 +69,8 @@ typedef struct fr_raster_cfg {
 	float scale_modifier;
 	int32_t sh_degree;   /* D */
 	int32_t sh_coeffs;   /* M = shs.size(1), 0 when colours are precomputed */
-	int32_t prefiltered; /* accepted for signature parity; the device trap of auxiliary.h:156-160 is not reproduced */
+	int32_t prefiltered; /* auxiliary.h:156-160: with it set, a point culled by the near plane is an error -- the reference traps the
+	                        device; fr_forward raises status[3] instead and the Python layer throws the reference's message */
 	const float* bg;
 	const float* viewmatrix;
 	const float* projmatrix;
@@ -113,7 +114,7 @@ int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
                     uint8_t* present, fr_stream_t stream);
 
 /* Forward.  binning_capacity = number of tile instances binning_ws can hold.  status (device int32[4]) receives
- * {num_rendered, overflow}; when num_rendered > binning_capacity nothing is rendered, overflow = 1 and the caller
+ * {num_rendered, overflow, longest tile list, prefiltered violated}; when num_rendered > binning_capacity nothing is rendered, overflow = 1 and the caller
  * re-runs with a larger buffer (the reference instead synchronises on num_rendered before sizing the buffer,
  * rasterizer_impl.cu:282-286).  out_color [3,H,W], out_depth [1,H,W], radii [P]. */
 int fr_forward(const fr_raster_cfg* cfg, const fr_gaussians* g,

@@ -242,6 +242,33 @@ def test_autograd_front_end_with_shs(gpu):
     assert torch.isfinite(t["scales"].grad).all() and torch.isfinite(t["rotations"].grad).all()
 
 
+def test_prefiltered_with_a_culled_point_is_an_error(gpu):
+    """auxiliary.h:156-160: with `prefiltered` set, a point behind the near plane makes the reference print "Point is filtered
+    although prefiltered is set" and trap the device.  Here the forward raises with that message and the device stays usable;
+    a scene with every point in front of the camera renders as without the flag."""
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings
+    P = 300
+    sc = random_scene(P, 41)
+    eye = torch.eye(4, device=gpu)
+    proj = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1.0001, 1], [0, 0, -0.01, 0]], dtype=torch.float32, device=gpu)
+
+    def render(means, prefiltered):
+        rs = GaussianRasterizationSettings(64, 64, 1.0, 1.0, torch.zeros(3, device=gpu), 1.0, eye, proj, 0, torch.zeros(3, device=gpu), prefiltered)
+        return GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros((P, 3), device=gpu), opacities=torch.tensor(sc["opacities"], device=gpu).reshape(-1, 1),
+                                      colors_precomp=torch.tensor(sc["colors"], device=gpu), scales=torch.tensor(sc["scales"], device=gpu),
+                                      rotations=torch.tensor(sc["rotations"], device=gpu))
+    means = torch.tensor(sc["means3D"], device=gpu)
+    assert float(means[:, 2].min()) > 0.001
+    a, b = render(means, False), render(means, True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    behind = means.clone()
+    behind[7, 2] = -1.0
+    with pytest.raises(RuntimeError, match="filtered although prefiltered is set"):
+        render(behind, True)
+    c = render(behind, False)                                  # without the flag the point is simply culled
+    assert int(c[1][7]) == 0 and torch.isfinite(c[0]).all()
+
+
 def test_fused_rgb_depth_silhouette_pair(gpu, oracle):
     """forward_pair / fr_forward_features / fr_backward_pair: the double render of the reference's get_loss
     (models/SLAM/gaussian.py:199-211) on one projection, binning and sort.  Forward images bit-identical to two separate
