@@ -3157,7 +3157,7 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	bool done = !inside;
 	uint32_t qh = 0, qn = 0;                       // ring head / fill, wave-uniform
 #ifdef FR_LOOPSTATS
-	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0, dbg_cs = 0;
+	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0, dbg_cs = 0, dbg_empty = 0;
 	long long dbg_t0 = 0, dbg_ts = 0, dbg_tc = 0, dbg_tw = 0;     // s_memtime sums: stream / chunk set-up / walk
 #endif
 
@@ -3270,6 +3270,9 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 #ifdef FR_LOOPSTATS
 		{ const long long t = (long long)__builtin_amdgcn_s_memtime(); dbg_tc += t - dbg_t0; }
 #endif
+#ifdef FR_LOOPSTATS
+		dbg_empty += (int)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)lane < m && emask == 0ull));      // parked candidates whose footprint misses every pixel of the strip
+#endif
 		// ---- refill the queue and start the next chunk's gathers before the transpose and the walk of this one
 		stream_fill();
 		gather_next();
@@ -3325,7 +3328,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 	{
 		// 2: candidates, 3: chunks, 4: wave-level walk iterations, 5: contributing pairs, 6: lane-level walk steps, 7: steps of the busiest lane
 		// 10 / 11 / 12: the wave's s_memtime ticks (/ 64) in the key stream / the chunk set-up / the walk
-		if (f.debug_mode == 13) ws = (float)(base < n ? base : n);            // keys this wave streamed before its 64 pixels were finished
+		if (f.debug_mode == 15) ws = (float)dbg_empty;                        // candidates parked with an empty footprint mask
+		else if (f.debug_mode == 13) ws = (float)(base < n ? base : n);            // keys this wave streamed before its 64 pixels were finished
 		else if (f.debug_mode == 14) ws = (float)n;                           // ... of the tile's n (both summed over the four waves)
 		else if (f.debug_mode >= 10) ws = (float)((f.debug_mode == 10 ? dbg_ts : f.debug_mode == 11 ? dbg_tc : dbg_tw) >> 6);
 		else
