@@ -615,13 +615,15 @@ struct FrRecordArgs {
 };
 // floats per Gaussian of the packed static record (k_pack_static): {mean 3, cov3D 6, rgb 3, (scale 3, rot 4), H_inv C}
 template <int C> struct FrPackSize { static constexpr int value = (C >= 11) ? 32 : 16; };
-template <int C, bool REWRITE, bool FORM_A = false>
+template <int C, bool REWRITE, bool FORM_A = false, bool FIVE = false>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c,
                                                      float4* out6 = nullptr, const float4* ab_src = nullptr);
 // float4 per compact record of a front-end mode: AF 0 = score form, 1 = A-form of k_fisher_tile_v3h, 2 = general out_H form
-template <int C, int AF> struct FrRecStride { static constexpr int value = AF == 2 ? (C >= 11 ? 13 : 7) : 6; };
+// (score form with fixed key segments: 5 -- the 80 bytes the walk parks, k3 in the place of the footprint extents, which the tile
+// kernel then no longer needs: its keys say which strips a splat reaches and the footprint rows come from the conic itself)
+template <int C, int AF, bool DK = false> struct FrRecStride { static constexpr int value = AF == 2 ? (C >= 11 ? 13 : 7) : ((AF == 0 && DK) ? 5 : 6); };
 template <int C>
 __device__ __forceinline__ void fr_fisher_record_general(const FrParams& p, const float* __restrict__ packed, int v, uint32_t id,
                                                          const float* vm, const float* pm, const float* wm, bool has_w2c,
@@ -909,7 +911,7 @@ template <int C, int AF, bool DK>
 __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, FrRecordArgs ra)
 {
 	static_assert((C == 4 || C == 11) && AF >= 0 && AF <= 2 && !(AF == 1 && C != 4), "records modes: score form, A-form (4 columns), general out_H form");
-	constexpr int RS = FrRecStride<C, AF>::value;     // float4 per compact record
+	constexpr int RS = FrRecStride<C, AF, DK>::value; // float4 per compact record
 	extern __shared__ uint32_t fr_dyn_lds[];     // hist[VC][T] | pairs[FR_THREADS * (VC + 1)] | wm[VC][12] | park[13][FR_THREADS] | DK: cursor[VC][T]
 	const int VC = p.VC;
 	uint32_t* hist = fr_dyn_lds;
@@ -1161,7 +1163,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				float4* rec_out = ra.comp + ((size_t)v * PV + slot) * RS;
 				FR_ABL(if (p.ablate == 37) rec_out = ra.comp + (size_t)tid * RS;)     // 37: the records' arithmetic without their HBM traffic
 				if constexpr (AF == 2) fr_fisher_record_general<C>(p, ra.packed, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
-				else fr_fisher_record_one<C, false, (AF == 1)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
+				else fr_fisher_record_one<C, false, (AF == 1), (AF == 0 && DK)>(p, ra.H_inv, ra.hinv_stride, ra.packed, ra.recq, v, idx, vm, pm, wm, has_w2c, rec_out, ab);
 				if constexpr (DK)
 				{
 					// 8-byte list entry {depth, x0 | y0 << 8 | width << 16 | height << 24}, y0 / height in strip rows (tile grids up to
@@ -2870,7 +2872,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 // ---------------------------------------------------------------------------------------------------------
 // REWRITE: the (view, Gaussian) record still holds the rasteriser's FrSplat and is turned into {recA, recB} here (stand-alone
 // k_fisher_records); otherwise the front end has already written {recA, recB} and only recQ is produced.
-template <int C, bool REWRITE, bool FORM_A>
+template <int C, bool REWRITE, bool FORM_A, bool FIVE>
 __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const float* __restrict__ H_inv, long long hinv_stride,
                                                      const float* __restrict__ packed, float4* __restrict__ recq, int v, uint32_t id,
                                                      const float* vm, const float* pm, const float* wm, bool has_w2c,
@@ -2944,6 +2946,16 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	{
 		sp[0] = make_float4(a0.x, a0.y, a1.w, __builtin_amdgcn_logf(a1.y));
 		sp[1] = make_float4(-0.5f * a0.z, -a0.w, -0.5f * a1.x, gsv[9] + gsv[10] + gsv[11]);
+	}
+	if constexpr (FIVE)
+	{
+		// the 80-byte record of the fixed-segment path: {x, y, k3, log2 o} {recB} {12 coefficients} -- what the walk parks
+		out6[0] = make_float4(ab_src[0].x, ab_src[0].y, k3, ab_src[0].w);
+		out6[1] = ab_src[1];
+		out6[2] = make_float4(qp[0], qp[1], qp[2], qp[3]);
+		out6[3] = make_float4(qp[4], qp[5], qp[6], qp[7]);
+		out6[4] = make_float4(qp[8], qp[9], qp[10], qp[11]);
+		return;
 	}
 	float4* dq = out6 ? out6 + 2 : recq + ((size_t)v * p.P + id) * 4;
 	dq[0] = make_float4(qp[0], qp[1], qp[2], qp[3]);
@@ -3210,7 +3222,8 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 			const uint32_t id = wq[(qh + lane) & (FR_QCAP - 1)];
 			pa = rec[rsA * id]; pb = rec[rsA * id + 1];
 			pq0 = rq[rsQ * id]; pq1 = rq[rsQ * id + 1]; pq2 = rq[rsQ * id + 2];
-			pk3 = ((const float*)(rq + rsQ * id + 3))[0];
+			if constexpr (MK) pk3 = pa.z;              // (the 80-byte record: k3 already sits where the walk wants it)
+			else pk3 = ((const float*)(rq + rsQ * id + 3))[0];
 		}
 		qh = (qh + pm) & (FR_QCAP - 1); qn -= pm;
 	};
@@ -3233,14 +3246,16 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 			ent[lane][1] = b4; ent[lane][2] = pq0; ent[lane][3] = pq1; ent[lane][4] = pq2;
 			const float ax = a.x, ay = a.y;
 			const uint32_t eb = __float_as_uint(a.z);
-			const float ahx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
-			const float ahy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+			// (MK: no extents in the record -- a listed splat's footprint rows come from the conic alone; a conic the quadratic
+			// cannot take covers the strip)
+			const float ahx = MK ? 1e30f : __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+			const float ahy = MK ? 1e30f : __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
 			const float acx = -2.0f * b4.x, acy = -b4.y, acz = -2.0f * b4.z;
 			// conservative lower bound on `power` below which alpha < 1/255: -ln(255 opacity) - 0.01 (fr_power_threshold)
 			const float athr = -(5.541263545158426f + 0.6931471805599453f * a.w) - 0.01f;
 			// Row by row: power(dx, dy) >= thr  <=>  cx dx^2 + 2 cy dy dx + (cz dy^2 + 2 thr) <= 0, an interval in dx
 			// (d = mean - pixel).  Widened by 1 % + 0.01 px, so it stays a superset of the exact test done in the walk.
-			const bool quad_ok = acx > 0.f && athr <= 0.f && ahx < 1e30f;
+			const bool quad_ok = acx > 0.f && athr <= 0.f && (MK || ahx < 1e30f);
 			const float racx = __builtin_amdgcn_rcpf(acx);
 #pragma unroll
 			for (unsigned r = 0; r < (unsigned)BH; r++)
@@ -6020,7 +6035,8 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		// FR_DEBUG_MODE 8 / 24: tile kernels that do not read the keys' strip bits)
 		const long long nblk_c = (P + FR_THREADS * fr_pick_G_views(P) - 1) / (FR_THREADS * fr_pick_G_views(P));
 		const bool slots_fit = nblk_c * FR_THREADS * fr_pick_G_views(P) < (1ll << 28);
-		if (p.gx <= 255u && p.gy <= 63u && slots_fit && fr_debug_mode() != 8 && fr_debug_mode() != 24) p.tile_cap = (uint32_t)fc->tile_capacity;
+		// (FR_DEBUG_MODE 20: the parking form of the projection kernel, which fills packed lists only)
+		if (p.gx <= 255u && p.gy <= 63u && slots_fit && fr_debug_mode() != 8 && fr_debug_mode() != 24 && fr_debug_mode() != 20) p.tile_cap = (uint32_t)fc->tile_capacity;
 	}
 	p.vis_count = fc->out_vis_count;
 	p.num_rendered = fc->out_num_rendered;
@@ -6050,7 +6066,9 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	plan.ra.packed = (const float*)(ws + L.packed); plan.ra.recq = (float4*)(ws + L.recq);
 	// compact records with the multi-view front end (the same condition fr_bin_pipeline uses for it); FR_DEBUG_MODE=19: dense (A/B runs)
 	const bool compact = (v3 || v3h || v3g) && multi_fe && f.debug_mode != 19;
-	const int rstride = v3g ? (fc->columns == 11 ? 13 : 7) : 6;
+	if (!compact) p.tile_cap = 0;                   // (fixed key segments are filled by the compact-record front end only)
+	// float4 per record: the general out_H forms 13 / 7, the score form 5 with fixed key segments (80 bytes: FrRecStride), else 6
+	const int rstride = v3g ? (fc->columns == 11 ? 13 : 7) : ((v3 && p.tile_cap) ? 5 : 6);
 	plan.ra.comp = compact ? (float4*)(ws + L.recq) : nullptr;
 	plan.ra.stride = rstride;
 	plan.ra.slot_idx = (compact && (v3h || v3g)) ? (uint32_t*)(ws + L.slot_idx) : nullptr;
