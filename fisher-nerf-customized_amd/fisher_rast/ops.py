@@ -391,7 +391,7 @@ class FisherScorer:
             status = status[0]
         return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv, dL_image))
 
-    def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None):
+    def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None, poses_are_c2w=False):
         """launch() + overflow handling.  Synchronises once (to read the 16-byte status word)."""
         w2c = w2c.reshape(-1, 4, 4)
         V = int(w2c.shape[0])
@@ -410,7 +410,7 @@ class FisherScorer:
                 dl = dL_image
                 if dL_image is not None and dL_image.dim() == 4 and dL_image.shape[0] == V:
                     dl = dL_image[v0:v1]
-                r = self.launch(w2c[v0:v1], hi, H_inv_per_view, oh, out_H_per_view, dl)
+                r = self.launch(w2c[v0:v1], hi, H_inv_per_view, oh, out_H_per_view, dl, poses_are_c2w)
                 st = r["status"].cpu()
                 if int(st[1]) == 0:
                     break

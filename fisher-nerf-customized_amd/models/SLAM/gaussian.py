@@ -200,7 +200,7 @@ class FisherOps:
             # the tile-instance buffer was too small (nothing was accumulated or scored): the growing path below repeats both
         H_train = self.compute_H_train(extra)
         H_train_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
-        res = scorer.run(torch.linalg.inv(c2w), H_inv=H_train_inv)
+        res = scorer.run(c2w, H_inv=H_train_inv, poses_are_c2w=True)
         scores = res["scores"].cpu()
         return scores, c2w
 
