@@ -35,7 +35,8 @@ import torch         # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-BYTES_PER_TILE_INSTANCE = 8 + 32 + 52   # k_fisher_tile_v3: sorted key + {recA, recB} + the 13 floats of recQ it uses, each moved once
+BYTES_PER_TILE_INSTANCE = 8 + 32 + 52   # k_fisher_tile_v3 on packed key lists: sorted key + {recA, recB} + the 13 floats of recQ it uses, each moved once
+BYTES_PER_TILE_INSTANCE_FIXED = 8 + 80  # ... with fixed key segments (the scorer's default): sorted key + the 80-byte record (20 floats, all used)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -457,7 +458,8 @@ def main():
         T = ((W + 15) // 16) * ((H + 15) // 16)
         # algorithmic bytes of ONE k_fisher_tile_v3 launch: per tile instance the sorted key (8 B), the
         # 32-byte {recA, recB} record and the 52 used bytes of the recQ record, each moved once; plus one partial score per (view, tile)
-        kern_bytes = (R * BYTES_PER_TILE_INSTANCE + 4.0 * V * T) / launches_per_step
+        per_instance = BYTES_PER_TILE_INSTANCE_FIXED if scorer.tile_capacity > 0 else BYTES_PER_TILE_INSTANCE
+        kern_bytes = (R * per_instance + 4.0 * V * T) / launches_per_step
         ach = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
         # whole-path algorithmic bytes per view, SURVEY.md 8(d)
         B_view = (12 * P + 44 * vis_count.mean() + 24 * num_rendered.mean() + 40 * num_rendered.mean() +
@@ -501,7 +503,7 @@ def main():
             "roofline": {"bound": "hbm", "binding": "valu", "kernel": "k_fisher_tile_v3", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
-                         "bytes_per_tile_instance": BYTES_PER_TILE_INSTANCE, "launches_per_step": launches_per_step,
+                         "bytes_per_tile_instance": per_instance, "launches_per_step": launches_per_step,
                          "views_per_launch": V // launches_per_step, "valu": valu, "valu_ceiling": ceil, "pmc": pmc_meta,
                          "note": "the kernel is bound by per-pair VALU work, not by bytes (no dense contraction, no MFMA): "
                                  "`valu.frac` = achieved wave64 VALU instructions per second over the calibrated ceiling"},
