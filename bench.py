@@ -327,6 +327,26 @@ def pmc_record(P, V, W, C):
     return (pm if meta["fresh"] else None), meta
 
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    bench.py <same arguments>` as a CHILD process (never a re-exec; nothing here has touched the GPU), pass its output through
+    and return its exit code.  The ranks rendezvous on 127.0.0.1 at a port that was free a moment ago."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:                                # rank 0's JSON line (and anything else the ranks print)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,12 +365,15 @@ def main():
                          "so its last bits differ from run to run; with fixed weights the scores of two runs can be compared bit for bit)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has made no GPU call; it starts the N ranks as a fresh child
+        # (torch.distributed.run, one process per GPU), relays rank 0's JSON line and exits with the child's code
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py --gpus {a.gpus} was started inside a process group of {world} rank(s)")
 
     import __graft_entry__ as entry
     P, W, H, C = a.gaussians, a.size, a.size, a.columns
@@ -388,10 +411,22 @@ def main():
 
     strong = a.total_views > 0
     V_total = a.total_views if strong else a.views * world
-    raw = synthetic.room_shell(P, seed)
-    act = synthetic.activate(raw)
+    # the map lives on ONE rank (the planner process of tester_gaussians_navigation.py:1618-1649 holds slam.params); the other
+    # ranks receive their replica by broadcast (once per planning round, outside the timed region)
+    raw, act, t_rep = None, None, 0.0
+    if rank == 0 or not dist_on:
+        raw = synthetic.room_shell(P, seed)
+        act = {k: v.to(dev) for k, v in synthetic.activate(raw).items()}
+    if dist_on:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_rep = time.perf_counter()
+        act, _ = D.replicate_map(act, None, src=0, device=dev)
+        torch.cuda.synchronize()
+        t_rep = time.perf_counter() - t_rep
+        D.assert_replicated([act[k] for k in sorted(act)])
     cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=dev)
-    scorer = FisherScorer(cam, *(act[k].to(dev) for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")),
+    scorer = FisherScorer(cam, *(act[k] for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")),
                           columns=C, dL_dpix=1e-3)
     w2c_all = synthetic.invert_rigid(synthetic.candidate_poses(V_total, seed)).to(dev)
     lo, hi = D.shard_bounds(V_total, rank, world)
@@ -557,7 +592,11 @@ def main():
             out["cpu_baseline"] = None
         if dist_on:
             out["collectives"] = {"backend": dist.get_backend(), "world_size": world,
-                                  "per_step": "all_gather_into_tensor of the per-view scores (fisher_rast.distributed.ScoreGather)"}
+                                  "per_step": "all_gather_into_tensor of the per-view scores (fisher_rast.distributed.ScoreGather)",
+                                  "replication": {"what": "fisher_rast.distributed.replicate_map: the activated map broadcast from rank 0, "
+                                                          "one dist.broadcast per tensor (outside the timed region)",
+                                                  "tensors": len(act), "bytes": int(sum(v.numel() * v.element_size() for v in act.values())),
+                                                  "ms": 1e3 * t_rep}}
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()

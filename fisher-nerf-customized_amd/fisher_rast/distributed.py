@@ -2,7 +2,8 @@
 `torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" on CPU for the tests).
 
 The reference has no distributed code; this is new work specified by section 8(e):
-  * Gaussian parameters and H_inv are REPLICATED on every rank (28 MB at 500k Gaussians);
+  * Gaussian parameters and H_inv are REPLICATED on every rank (28 MB + 8 MB at 500k Gaussians): `replicate_map` broadcasts
+    them from the one process that holds `slam.params` (tester_gaussians_navigation.py:1618-1649), once per planning round;
   * candidate views are partitioned contiguously; every rank scores its slice with FisherScorer;
   * ONE all-gather of the per-view scalar scores (V/world floats per rank: latency-bound, a single direct exchange);
   * H_train = keyframes sharded across ranks + ONE all-reduce(SUM) of the [P, C] fp32 accumulator.
@@ -40,6 +41,78 @@ def _world(group=None):
 def _host_collectives(t: torch.Tensor, group=None) -> bool:
     """gloo (the CPU rehearsal backend) is driven with host tensors; nccl (RCCL) takes the device tensors as they are."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _broadcast(t: torch.Tensor, src: int, group=None):
+    if _host_collectives(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
+def replicate_map(params: Optional[dict], H_inv: Optional[torch.Tensor] = None, src: int = 0, group=None, device=None):
+    """SURVEY 8(e) "replicate ... (broadcast once per planning round)": rank `src` holds the map (a dict name -> tensor, e.g.
+    `slam.params` or the activated render variables) and optionally H_inv; every other rank may pass None (or stale tensors of
+    any content).  One small object broadcast carries names / shapes / dtypes, then ONE `dist.broadcast` per tensor
+    (28 MB + 8 MB at 500k Gaussians).  Returns `(params, H_inv)` on every rank: on `src` the caller's own tensors, elsewhere
+    tensors on `device` (reused when the caller passed tensors of the right shape / dtype / device)."""
+    rank, world = _world(group)
+    if not _collective(world):
+        return params, H_inv
+    if rank == src:
+        items = [(k, v) for k, v in params.items() if torch.is_tensor(v)]
+        meta = [[(k, tuple(v.shape), v.dtype) for k, v in items], None if H_inv is None else (tuple(H_inv.shape), H_inv.dtype)]
+    else:
+        meta = [None, None]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    if device is None:
+        device = next(iter(params.values())).device if params else torch.device("cpu")
+
+    def _slot(old, shape, dtype):
+        if rank == src:
+            return old.detach().contiguous()
+        if torch.is_tensor(old) and tuple(old.shape) == shape and old.dtype == dtype and old.device == torch.device(device) and old.is_contiguous():
+            return old.detach()
+        return torch.empty(shape, dtype=dtype, device=device)
+
+    out = {} if rank != src else dict(params)
+    for name, shape, dtype in meta[0]:
+        t = _slot(params.get(name) if params else None, shape, dtype)
+        _broadcast(t, src, group)
+        if rank != src:
+            out[name] = t
+    if meta[1] is not None:
+        h = _slot(H_inv, *meta[1])
+        _broadcast(h, src, group)
+        H_inv = H_inv if rank == src else h
+    return out, H_inv
+
+
+def map_fingerprint(tensors) -> torch.Tensor:
+    """One fp64 number per tensor (its sum and its sum of squares folded): equal on two ranks iff the replicas agree (up to the
+    astronomically unlikely collision).  NaNs are mapped to a fixed value so that two equal maps with NaNs still compare equal."""
+    vals = []
+    for t in tensors:
+        d = torch.nan_to_num(t.detach().double().reshape(-1), nan=12345.0, posinf=1e300, neginf=-1e300)
+        w = torch.arange(1, d.numel() + 1, dtype=torch.float64, device=d.device) * 1e-6
+        vals += [d.sum(), (d * w).sum()]
+    return torch.stack(vals) if vals else torch.zeros((0,), dtype=torch.float64)
+
+
+def assert_replicated(tensors, group=None, what: str = "Gaussian map"):
+    """Raise on EVERY rank when the ranks' replicas differ (two all-reduces of a few doubles: MIN and MAX of the fingerprint)."""
+    rank, world = _world(group)
+    if not _collective(world):
+        return
+    fp = map_fingerprint(tensors)
+    lo, hi = fp.clone(), fp.clone()
+    _all_reduce(lo, dist.ReduceOp.MIN, group)
+    _all_reduce(hi, dist.ReduceOp.MAX, group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"{what}: the ranks hold different replicas (fingerprints differ) -- call "
+                           f"fisher_rast.distributed.replicate_map() before sharding the views")
 
 
 class ScoreGather:
@@ -150,9 +223,13 @@ def sharded_point_score_max(scorer, w2c_all: torch.Tensor, H_inv: torch.Tensor, 
     return best
 
 
-def pose_eval_sharded(scorer, kf_w2c: torch.Tensor, w2c_all: torch.Tensor, reg: float = 0.1, group=None):
+def pose_eval_sharded(scorer, kf_w2c: torch.Tensor, w2c_all: torch.Tensor, reg: float = 0.1, group=None, check_replicas: bool = True):
     """GaussianSLAM.pose_eval (gaussian.py:1354-1375) over the ranks of a node.  `scorer` is a FisherScorer holding
-    this rank's replica of the map."""
+    this rank's replica of the map (built from what `replicate_map` returned).  `check_replicas`: compare a fingerprint of the
+    replicas and of the poses across the ranks first (two tiny all-reduces) and raise instead of returning scores of
+    different maps."""
+    if check_replicas:
+        assert_replicated([scorer.means3D, scorer.colors, scorer.rotations, scorer.opacities, scorer.scales, kf_w2c, w2c_all], group)
     H_train = torch.zeros((scorer.P, scorer.columns), dtype=torch.float32, device=scorer.dev)
     sharded_h_train(lambda w, H: scorer.run(w, out_H=H), kf_w2c, H_train, group)
     H_inv = torch.reciprocal(H_train + reg)

@@ -9,7 +9,6 @@ Three groups of entry points:
   * `knn_dist2` -- simple_knn._C.distCUDA2.
 """
 import ctypes
-import os
 from typing import Optional
 
 import torch
@@ -248,7 +247,7 @@ class FisherScorer:
     MAX_KEY_BYTES_PER_VIEW = 512 << 20  # fixed key segments beyond this per view: packed lists instead (tile_capacity = 0)
 
     def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
-                 dL_dpix: float = 1e-3):
+                 dL_dpix: float = 1e-3, tile_capacity: int = 16384):
         _need_gpu(means3D, "means3D")
         if columns not in (4, 11):
             raise ValueError("columns must be 4 or 11")
@@ -271,17 +270,13 @@ class FisherScorer:
         self.proj = _prep(raster_settings.projmatrix, d)
         self.campos = _prep(raster_settings.campos, d)
         self._ws = {}
-        self._side_streams = []
-        # measured on MI355X (500k Gaussians, 64 views; round 3 kernels): 2 groups on 2 streams 2.47 ms per step against 2.08 ms for
-        # one launch, 4 groups 2.76 ms (the staggered form inside fr_fisher_views, FR_GROUPS: 2.32 / 2.56) -- one group is the default
-        self.n_streams = max(1, int(os.environ.get("FR_STREAMS", "1")))
         self.per_view_capacity = max(int(0.75 * self.P), 1 << 16)
         # Fixed key segments (fr_fisher_cfg.tile_capacity): every (view, tile) owns `tile_capacity` key slots, the projection
         # kernel places the keys itself and the scan / scatter kernels drop out of the launch sequence.  16384 keys (the largest
         # list the in-LDS sort tiers take) x 8 B = 128 KiB per tile -- 32 MiB per 256 x 256 view of the 288 GB; a longer list
         # raises the overflow flag and `run` grows the segments, or goes back to packed lists where they would not fit.
         self.tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        self.tile_capacity = int(os.environ.get("FR_TILE_CAPACITY", "16384"))
+        self.tile_capacity = int(tile_capacity)            # 0: packed key lists
         if self.tiles * self.tile_capacity * 8 > self.MAX_KEY_BYTES_PER_VIEW:
             self.tile_capacity = 0
         self.cfg = _raster_cfg(self.P, self.H, self.W, raster_settings.tanfovx, raster_settings.tanfovy,
@@ -314,11 +309,7 @@ class FisherScorer:
     def launch(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None, poses_are_c2w=False):
         """Enqueue one batch (no sync).  w2c: [V,4,4] world->camera on the device (camera->world with `poses_are_c2w`: the
         library inverts them).
-        Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4].
-
-        The batch is cut into `self.n_streams` groups of views that run on separate HIP streams with separate
-        workspaces: the binning kernels of one group (latency-bound, few waves) overlap the tile kernel of the other
-        (VALU-bound).  Groups are whole multiples of 8 views so that the XCD-aware tile mapping stays exact."""
+        Returns a dict of device tensors: scores [V] (if H_inv), vis_count [V], num_rendered [V], status [4]."""
         d = self.dev
         w2c = _prep(w2c.reshape(-1, 4, 4), d)
         V = int(w2c.shape[0])
@@ -346,49 +337,34 @@ class FisherScorer:
         # zero-filled / fully written by the library itself (k_zero_many, k_scan_tiles, k_reduce_scores): no fill kernels here
         vis = torch.empty((V,), dtype=torch.int32, device=d)
         nr = torch.empty((V,), dtype=torch.int32, device=d)
-        n_groups = self.n_streams if (V >= 16 * self.n_streams and V % (8 * self.n_streams) == 0) else 1
-        status = torch.empty((n_groups, 4), dtype=torch.int32, device=d)
-        per = V // n_groups
-        cur = torch.cuda.current_stream(d)
-        if n_groups > 1 and len(self._side_streams) < n_groups - 1:
-            self._side_streams = [torch.cuda.Stream(device=d) for _ in range(n_groups - 1)]
+        status = torch.empty((4,), dtype=torch.int32, device=d)
+        # ONE fr_fisher_views call per launch: a call accumulates into out_H all or nothing (overflow: nothing), which is what lets
+        # `run` simply redo a batch.  (Round 3 could cut a batch into view groups on separate streams; it measured slower -- 2.47 ms
+        # against 2.08 ms per step -- and a group that had not overflowed would have been added to out_H twice by the redo.)
+        max_rendered = V * self._keys_per_view()
+        ws = self._workspace(V, max_rendered)
+        fc = FisherCfg()
+        fc.n_views, fc.columns, fc.dL_dpix = V, C, self.dL
+        fc.poses_are_c2w = 1 if poses_are_c2w else 0
+        fc.tile_capacity = self.tile_capacity if V * self.tiles * self.tile_capacity < (1 << 32) else 0
+        fc.w2c = ctypes.c_void_p(w2c.data_ptr())
+        if H_inv is not None:
+            fc.H_inv = ctypes.c_void_p(H_inv.data_ptr())
+            fc.H_inv_view_stride = PC if H_inv_per_view else 0
+            fc.out_scores = ctypes.c_void_p(scores.data_ptr())
+        if out_H is not None:
+            fc.out_H = ctypes.c_void_p(out_H.data_ptr())
+            fc.out_H_view_stride = PC if out_H_per_view else 0
+        if dL_image is not None:
+            fc.dL_dpix_image = ctypes.c_void_p(dL_image.data_ptr())
+            fc.dL_image_view_stride = HW3 if dL_image.numel() != HW3 else 0
+        fc.out_vis_count = vis.data_ptr()
+        fc.out_num_rendered = nr.data_ptr()
         with torch.cuda.device(d):
-            for gi in range(n_groups):
-                v0, v1 = gi * per, (gi + 1) * per
-                stream = cur if gi == 0 else self._side_streams[gi - 1]
-                if gi > 0:
-                    stream.wait_stream(cur)
-                Vg = v1 - v0
-                max_rendered = Vg * self._keys_per_view()
-                ws = self._workspace(Vg, max_rendered, gi)
-                fc = FisherCfg()
-                fc.n_views, fc.columns, fc.dL_dpix = Vg, C, self.dL
-                fc.poses_are_c2w = 1 if poses_are_c2w else 0
-                fc.tile_capacity = self.tile_capacity if Vg * self.tiles * self.tile_capacity < (1 << 32) else 0
-                fc.w2c = ctypes.c_void_p(w2c.data_ptr() + v0 * 64)
-                if H_inv is not None:
-                    fc.H_inv = ctypes.c_void_p(H_inv.data_ptr() + (v0 * PC * 4 if H_inv_per_view else 0))
-                    fc.H_inv_view_stride = PC if H_inv_per_view else 0
-                    fc.out_scores = ctypes.c_void_p(scores.data_ptr() + v0 * 4)
-                if out_H is not None:
-                    fc.out_H = ctypes.c_void_p(out_H.data_ptr() + (v0 * PC * 4 if out_H_per_view else 0))
-                    fc.out_H_view_stride = PC if out_H_per_view else 0
-                if dL_image is not None:
-                    per_view = dL_image.numel() != HW3
-                    fc.dL_dpix_image = ctypes.c_void_p(dL_image.data_ptr() + (v0 * HW3 * 4 if per_view else 0))
-                    fc.dL_image_view_stride = HW3 if per_view else 0
-                fc.out_vis_count = vis.data_ptr() + v0 * 4
-                fc.out_num_rendered = nr.data_ptr() + v0 * 4
-                _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
-                                                    ws.data_ptr(), ws.numel(), max_rendered,
-                                                    status.data_ptr() + gi * 16, ctypes.c_void_p(stream.cuda_stream)),
-                           "fr_fisher_views")
-            for gi in range(1, n_groups):
-                cur.wait_stream(self._side_streams[gi - 1])
-        if n_groups > 1:
-            status = torch.stack([status[:, 0].sum(), status[:, 1].max(), status[:, 2].max(), status[:, 3].max()]).to(torch.int32)
-        else:
-            status = status[0]
+            _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
+                                                ws.data_ptr(), ws.numel(), max_rendered,
+                                                status.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream)),
+                       "fr_fisher_views")
         return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv, dL_image))
 
     def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None, poses_are_c2w=False):

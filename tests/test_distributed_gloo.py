@@ -93,3 +93,57 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _replicate_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "fisher-nerf-customized_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fisher_rast import distributed as D, synthetic
+        P = 700
+        full = synthetic.room_shell(P, seed=9)                       # what only the planner process holds (slam.params)
+        H_full = torch.rand((P, 4), generator=torch.Generator().manual_seed(3))
+        if rank == 0:
+            params, H_inv = full, H_full
+        elif rank == 1:
+            params, H_inv = None, None                               # a worker rank with no map at all
+        else:
+            params = {k: torch.zeros_like(v) for k, v in full.items()}   # a stale replica: zeros of the right shape are reused in place
+            H_inv = torch.zeros((P, 4))
+        stale_ptr = None if params is None or rank == 0 else params["means3D"].data_ptr()
+        # the replicas differ before the broadcast: the fingerprint check must say so on every rank
+        mine = [v for v in (params or {"x": torch.zeros(3)}).values()]
+        differs = False
+        try:
+            D.assert_replicated(mine[:1])
+        except RuntimeError as ex:
+            differs = "different replicas" in str(ex)
+        got, H_got = D.replicate_map(params, H_inv, src=0, device=torch.device("cpu"))
+        D.assert_replicated([got[k] for k in sorted(got)] + [H_got])
+        ok = all(torch.equal(got[k], full[k]) for k in full) and torch.equal(H_got, H_full) and set(got) == set(full)
+        reused = stale_ptr is None or got["means3D"].data_ptr() == stale_ptr
+        torch.save(dict(ok=ok, differs=differs, reused=reused), os.path.join(out_dir, f"rep{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicate_map_world3(tmp_path):
+    """the map and H_inv are broadcast from the one rank that holds them; a rank that starts from nothing (None) or
+    from zeros ends with rank 0's tensors bit for bit, and `assert_replicated` tells differing replicas from equal ones."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_replicate_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        d = torch.load(tmp_path / f"rep{r}.pt")
+        assert d["ok"] and d["differs"] and d["reused"], (r, d)
+
+
+def test_replicate_map_is_identity_without_a_process_group():
+    from fisher_rast import distributed as D
+    p = {"a": torch.ones(3)}
+    got, h = D.replicate_map(p, None)
+    assert got is p and h is None
+    D.assert_replicated([p["a"]])

@@ -46,6 +46,24 @@ def test_two_rank_bench_equals_one_rank(gpu, tmp_path):
     assert one["n_gpus"] == 1 and one["build"]["build_id"].startswith("FRSRC:")
 
 
+def test_plain_command_starts_its_own_ranks(gpu, tmp_path):
+    """The driver's command form, no launcher: `python bench.py --gpus 2 ...` must start its two ranks itself (a fresh
+    torch.distributed.run child; the parent never touches the GPU), replicate the map from rank 0 by broadcast, shard the 16
+    views, and print ONE JSON line whose `collectives` shows that two ranks took part.  Scores = the 1-rank run, bit for bit."""
+    one, s1 = _run([sys.executable, "bench.py", "--gpus", "1", "--views", "16"] + COMMON, {}, str(tmp_path / "one.npy"))
+    env = {"FR_BENCH_BACKEND": "gloo", "FR_BENCH_ONE_DEVICE": "1"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        assert k not in os.environ
+    two, s2 = _run([sys.executable, "bench.py", "--gpus", "2", "--total-views", "16"] + COMMON, env, str(tmp_path / "two.npy"))
+    assert two["n_gpus"] == 2 and two["collectives"]["world_size"] == 2 and two["collectives"]["backend"] == "gloo"
+    rep = two["collectives"]["replication"]
+    assert rep["tensors"] == 5 and rep["bytes"] == 30000 * 4 * (3 + 3 + 4 + 1 + 3)
+    assert two["config"]["views_total"] == 16 and two["config"]["views_per_gpu"] == 8 and two["scaling"] == "strong"
+    assert np.array_equal(s1, s2)
+    weak, sw = _run([sys.executable, "bench.py", "--gpus", "2", "--views", "8"] + COMMON, env, str(tmp_path / "weak.npy"))
+    assert weak["scaling"] == "weak" and weak["config"]["views_total"] == 16 and np.array_equal(sw, s1)
+
+
 def test_one_rank_process_group_runs_the_collectives_through_rccl(gpu, tmp_path):
     """No multi-GPU node here, but the transport can still be exercised: bench.py under torch.distributed.run with ONE rank and
     the nccl backend (= RCCL), FR_FORCE_COLLECTIVES=1: the process group is created, the H_train all-reduce and the per-step
