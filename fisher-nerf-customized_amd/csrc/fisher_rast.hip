@@ -54,7 +54,22 @@
 #include <vector>
 #include <utility>
 static thread_local char g_err[512] = "";
+// The PRODUCT build (__graft_entry__.build()) reads no environment variable and holds only kernels a default call can reach.
+// -DFR_AB (tools/build_variant.sh -> tools/_build/, loaded through FISHER_RAST_SO by tools/ab.sh, loopstats.py, fe_ablate.py) is the
+// experiment rig: FR_DEBUG_MODE / FR_GV / FR_VC / FR_GROUPS / FR_TILE_PRIO and the kernel generations only those switches select.
+#if defined(FR_ABLATE) || defined(FR_LOOPSTATS)
+#ifndef FR_AB
+#define FR_AB
+#endif
+#endif
+#ifdef FR_AB
+#define FR_AB_ONLY(x) x
 static int fr_debug_mode();
+static int fr_env_int(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#else
+#define FR_AB_ONLY(x)
+static constexpr int fr_debug_mode() { return 0; }
+#endif
 // measurement only: HIP events recorded around the dominant kernel on the stream it is launched on
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
@@ -1692,6 +1707,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 	const uint32_t n = p.tile_cnt[vt];
 	if (n < 2 || n > (uint32_t)FR_SORT_SMALL_KEYS) return;
 	uint64_t* gk = p.keys + p.tile_off[vt];
+#ifdef FR_AB
 	if (p.legacy_sort)
 	{
 		for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
@@ -1700,6 +1716,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 		for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
 		return;
 	}
+#endif
 	if (n <= 512u)
 	{
 		if (tid >= 64) return;
@@ -1731,6 +1748,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
 		if (n > (uint32_t)FR_SORT_MID_KEYS) continue;
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
+#ifdef FR_AB
 		if (p.legacy_sort)
 		{
 			for (uint32_t i = tid; i < n; i += FR_THREADS) skeys[i] = gk[i];
@@ -1738,7 +1756,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
 			fr_bitonic(skeys, n, tid, FR_THREADS);
 			for (uint32_t i = tid; i < n; i += FR_THREADS) gk[i] = skeys[i];
 		}
-		else fr_sort_wg_segment<16, 4>(skeys, gk, n, tid);
+		else
+#endif
+		fr_sort_wg_segment<16, 4>(skeys, gk, n, tid);
 	}
 }
 
@@ -1756,6 +1776,7 @@ __global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
 		if (n > (uint32_t)FR_SORT_BIG_KEYS) fr_bitonic(gk, n, tid, 1024);
+#ifdef FR_AB
 		else if (p.legacy_sort)
 		{
 			for (uint32_t i = tid; i < n; i += 1024) skeys[i] = gk[i];
@@ -1763,6 +1784,7 @@ __global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
 			fr_bitonic(skeys, n, tid, 1024);
 			for (uint32_t i = tid; i < n; i += 1024) gk[i] = skeys[i];
 		}
+#endif
 		else if (n <= 8192u) fr_sort_wg_segment<8, 16>(skeys, gk, n, tid);
 		else fr_sort_wg_segment<16, 16>(skeys, gk, n, tid);
 	}
@@ -2479,7 +2501,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(C ==
 		return;
 	}
 	if (tid == 0) fallback[vt] = 0;
-	if (f.debug_mode == 1) { if (tid == 0) f.tile_scores[vt] = (float)wcnt; return; }
+	FR_AB_ONLY(if (f.debug_mode == 1) { if (tid == 0) f.tile_scores[vt] = (float)wcnt; return; })
 
 	// ---- pass 2: wave-private, back to front ----
 	// 64 list entries at a time, one per lane: the lane gathers its splat and the packed static record and pushes unit
@@ -3441,6 +3463,7 @@ __device__ __forceinline__ unsigned long long fr_footprint_mask(const float4& a,
 	return emask;
 }
 
+#ifdef FR_AB
 // ---------------------------------------------------------------------------------------------------------
 // k_fisher_tile_v3 with a ROLLING WINDOW of two chunks (experiment, FR_DEBUG_MODE=24; NOT the default).  In k_fisher_tile_v3 the
 // wave re-converges after every chunk of 64 candidates, so every chunk costs as many walk iterations as its busiest pixel-lane has
@@ -3637,6 +3660,7 @@ void k_fisher_tile_v3w(FrParams p, FrFisherArgs f)
 	__syncthreads();
 	if (tid == 0) f.tile_scores[vt] = (__uint_as_float(s_q[0][0]) + __uint_as_float(s_q[1][0])) + (__uint_as_float(s_q[2][0]) + __uint_as_float(s_q[3][0]));
 }
+#endif   // FR_AB
 
 // ---------------------------------------------------------------------------------------------------------
 // Forward compositing with the scorer's walk (k_fisher_tile_v3): the wave streams the tile's keys, keeps the splats whose
@@ -5152,9 +5176,10 @@ static inline int fr_pick_G(long long P, long long V)
 // multi-view front end: 256*G Gaussians x VC views per workgroup
 static inline int fr_pick_G_views(long long P)
 {
-	static int forced = -1;                                   // FR_GV=<n>: A/B runs
-	if (forced < 0) { const char* e = getenv("FR_GV"); forced = e ? atoi(e) : 0; }
+#ifdef FR_AB
+	static const int forced = fr_env_int("FR_GV");            // FR_GV=<n>: A/B runs
 	if (forced > 0) return forced > 8 ? 8 : forced;
+#endif
 	// ~400 workgroups along P.  (Measured on MI355X, 500k Gaussians x 64 views, ms per step, round 2: G = 1: 2.24, 2: 2.20, 3: 2.17-2.20,
 	// 4: 2.19-2.22, 7: 2.26, 10: 2.37; round 3, with the survivors of the 256-Gaussian rounds batched across rounds and the key
 	// scatter at the end of the workgroup: G = 2: 1.69, 3: 1.69-1.72, 5: 1.67-1.68, 6: 1.68-1.70, 8: 1.68-1.70.)
@@ -5163,11 +5188,12 @@ static inline int fr_pick_G_views(long long P)
 }
 static inline int fr_pick_VC(long long T)
 {
-	static int forced = -1;                                   // FR_VC=<n>: A/B runs
-	if (forced < 0) { const char* e = getenv("FR_VC"); forced = e ? atoi(e) : 0; }
 	long long vc = 8192 / (T < 1 ? 1 : T);
 	if (vc > FR_VC_MAX) vc = FR_VC_MAX;                       // the kernel's per-view counters (s_n / s_ref) hold FR_VC_MAX views
+#ifdef FR_AB
+	static const int forced = fr_env_int("FR_VC");            // FR_VC=<n>: A/B runs
 	if (forced > 0) return (int)(forced > vc ? (vc < 1 ? 1 : vc) : forced);
+#endif
 	if (vc > 4) vc = 4;                                       // 4 views per workgroup: 2.16 ms per step against 2.20 for 8 and 2.19 for 2
 	return (int)(vc < 1 ? 1 : (vc > 8 ? 8 : vc));
 }
@@ -5178,12 +5204,30 @@ static inline int fr_pick_VC(long long T)
 // the tile stream at the lowest or the highest priority: the same).  Both halves want the same wave slots and the same L2.
 static inline int fr_pick_groups(int V)
 {
-	static int forced = -1;
-	if (forced < 0) { const char* e = getenv("FR_GROUPS"); forced = e ? atoi(e) : 0; }
+#ifdef FR_AB
+	static const int forced = fr_env_int("FR_GROUPS");
 	int n = forced > 0 ? forced : 1;
 	if (n > 4) n = 4;                                         // FR_MAX_GROUPS
 	while (n > 1 && V < 16 * n) n--;                          // at least 16 views per group
 	return n;
+#else
+	(void)V;
+	return 1;
+#endif
+}
+// LDS bytes of k_preprocess_views_c for vc views per workgroup (fixed key segments keep a second [vc][T] array, the cursors)
+static inline size_t fr_lds_views_c(int vc, int T, bool fixed)
+{
+	return ((size_t)vc * T * (fixed ? 2 : 1) + (size_t)FR_THREADS * (vc + 1) + 12 * (size_t)vc + 13 * (size_t)FR_THREADS) * 4;
+}
+// Views per workgroup of k_preprocess_views_c, and whether fixed key segments stay: fewer views where the LDS would pass 64 KiB,
+// packed lists (tile_cap = 0) where even one view does not fit.  ONE place decides this -- fr_fisher_views calls it before it fixes
+// the record stride (the 80-byte score records exist with fixed segments only), fr_bin_pipeline calls it again and gets the same answer.
+static inline int fr_plan_views_c(int T, int vc, uint32_t& tile_cap)
+{
+	while (tile_cap && vc > 1 && fr_lds_views_c(vc, T, true) > 65536) vc >>= 1;
+	if (tile_cap && fr_lds_views_c(vc, T, true) > 65536) tile_cap = 0;
+	return vc;
 }
 static inline long long fr_preprocess_blocks(long long P, long long V)
 {
@@ -5346,7 +5390,11 @@ static FrSideStream& fr_side_stream(int which = 0)
 	{
 		if (ss.ok) { (void)hipEventDestroy(ss.fork); (void)hipEventDestroy(ss.join); (void)hipStreamDestroy(ss.stream); }
 		// FR_TILE_PRIO=<-1|0|1> (A/B runs): priority of the tile stream [2] relative to the default: 1 = lowest, -1 = highest
-		static const int tile_prio = [] { const char* e = getenv("FR_TILE_PRIO"); return e ? atoi(e) : 0; }();
+#ifdef FR_AB
+		static const int tile_prio = fr_env_int("FR_TILE_PRIO");
+#else
+		constexpr int tile_prio = 0;
+#endif
 		int lo = 0, hi = 0;
 		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least priority (largest number), hi = greatest
 		const int prio = (which == 2 && tile_prio > 0) ? lo : (which == 2 && tile_prio < 0) ? hi : 0;
@@ -5426,10 +5474,11 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		// compact records: written once, in place, by k_preprocess_views_c (FR_DEBUG_MODE=20 keeps the parking form for A/B runs)
 		const bool once = plan && plan->ra.comp != nullptr && fr_debug_mode() != 20;
 		if (!once) p.tile_cap = 0;                       // fixed key segments are filled by k_preprocess_views_c only
-		// (fixed segments keep a second [VC][T] array in LDS, the cursors: fewer views per workgroup where that would pass 64 KiB)
-		auto lds_c_of = [&](int vc) { return ((size_t)vc * p.T * (p.tile_cap ? 2 : 1) + (size_t)FR_THREADS * (vc + 1) + 12 * (size_t)vc + 13 * (size_t)FR_THREADS) * 4; };
-		while (once && p.tile_cap && p.VC > 1 && lds_c_of(p.VC) > 65536) p.VC >>= 1;
-		if (once && p.tile_cap && lds_c_of(p.VC) > 65536) p.tile_cap = 0;
+		const bool wanted_fixed = p.tile_cap != 0;
+		if (once) p.VC = fr_plan_views_c(p.T, p.VC, p.tile_cap);
+		// (fr_fisher_views has taken the same decision before it fixed the record stride: the 80-byte score records go with fixed segments)
+		if (once && wanted_fixed && !p.tile_cap) return fr_fail(FR_EINVAL, "fr_bin_pipeline: fixed key segments planned, but they do not fit the LDS");
+		auto lds_c_of = [&](int vc) { return fr_lds_views_c(vc, p.T, p.tile_cap != 0); };
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 2 * (size_t)p.VC * 8 * (size_t)p.G) * 4;
 		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 6 };
@@ -5449,9 +5498,13 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		else if (once && dk) hipLaunchKernelGGL((k_preprocess_views_c<11, 0, true>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (once) hipLaunchKernelGGL((k_preprocess_views_c<11, 0, false>), gridV, dim3(FR_THREADS), lds_c, s, p, ra);
 		else if (!plan) hipLaunchKernelGGL((k_preprocess_views<0, false>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+#ifdef FR_AB
 		else if (plan->form_a) hipLaunchKernelGGL((k_preprocess_views<-4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else if (plan->columns == 4) hipLaunchKernelGGL((k_preprocess_views<4, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
 		else hipLaunchKernelGGL((k_preprocess_views<11, true>), gridV, dim3(FR_THREADS), lds, s, p, ra);
+#else
+		else return fr_fail(FR_EINVAL, "fr_bin_pipeline: a records plan of the multi-view front end needs compact records");
+#endif
 		if ((rc = fr_check_launch("k_preprocess_views"))) return rc;
 	}
 	else
@@ -5546,12 +5599,15 @@ static int fr_forward_impl(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	p.key_capacity = binning_capacity;
 	if ((rc = fr_bin_pipeline(p, g, s))) return rc;
 	const float* feat = g->colors_precomp ? g->colors_precomp : p.rgb;
-	const bool bcast = fr_debug_mode() == 16;        // FR_DEBUG_MODE=16: the wave-uniform compositing kernel of round 1 (A/B runs)
+	FR_AB_ONLY(const bool bcast = fr_debug_mode() == 16;)        // FR_DEBUG_MODE=16: the wave-uniform compositing kernel of round 1 (A/B runs)
 	float* fT = (float*)((char*)image_ws + L.final_T);
 	uint32_t* nC = (uint32_t*)((char*)image_ws + L.n_contrib);
-	if (features2 && bcast) hipLaunchKernelGGL((k_render_forward<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, features2, out_features2);
-	else if (features2) hipLaunchKernelGGL((k_render_forward_walk<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, features2, out_features2);
+#ifdef FR_AB
+	if (bcast && features2) hipLaunchKernelGGL((k_render_forward<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, features2, out_features2);
 	else if (bcast) hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, (const float*)nullptr, (float*)nullptr);
+	else
+#endif
+	if (features2) hipLaunchKernelGGL((k_render_forward_walk<6>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, features2, out_features2);
 	else hipLaunchKernelGGL((k_render_forward_walk<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, feat, 0, fT, nC, out_color, out_depth, (const float*)nullptr, (float*)nullptr);
 	if ((rc = fr_check_launch("k_render_forward"))) return rc;
 	(void)hipMemcpyAsync(status, p.status, 16, hipMemcpyDeviceToDevice, s);
@@ -5624,6 +5680,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		// index are redone (u only) by the scan kernel.  The flag array borrows tile_fill, which is dead after binning.
 		// FR_DEBUG_MODE=17: the two-pass tile kernel of round 1 with its fallback pass (A/B runs); k_backward_lin_walk has no list
 		// capacity and therefore no fallback tiles
+#ifdef FR_AB
 		if (fr_debug_mode() == 17)
 		{
 			uint8_t* fallback = (uint8_t*)p.tile_fill;
@@ -5638,6 +5695,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 			if ((rc = fr_check_launch("k_backward_tile(flagged)"))) return rc;
 		}
 		else
+#endif
 		{
 			hipLaunchKernelGGL((k_backward_lin_walk<false>), dim3(p.T), block, 0, s, p, b);
 			if ((rc = fr_check_launch("k_backward_lin_walk"))) return rc;
@@ -5661,6 +5719,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		hipLaunchKernelGGL(k_backward_sq_walk, dim3(p.T), block, 0, s, p, b, (const float*)rows);
 		return fr_check_launch("k_backward_sq_walk");
 	}
+#ifdef FR_AB
 	if (power == 2 && sr && !sh && g->colors_precomp && !g->cov3D_precomp)
 	{
 		// The diagonal Fisher proxy as the reference's own loop asks for it (gaussian.py:1536-1556: one view, autograd, power 2):
@@ -5682,6 +5741,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
 		return fr_check_launch("k_backward_tile(flagged)");
 	}
+#endif
 	if (sr && sh) hipLaunchKernelGGL((k_backward_tile<true, true>), grid, block, 0, s, p, b);
 	else if (sr) hipLaunchKernelGGL((k_backward_tile<true, false>), grid, block, 0, s, p, b);
 	else if (sh) hipLaunchKernelGGL((k_backward_tile<false, true>), grid, block, 0, s, p, b);
@@ -5717,11 +5777,13 @@ extern "C" int fr_forward_features(const fr_raster_cfg* cfg, const float* featur
 	FrParams p;
 	fr_fill_params(p, cfg, &g0, 1);
 	fr_carve_single(p, L, (char*)geom_ws, (char*)binning_ws, (char*)image_ws);
+#ifdef FR_AB
 	if (fr_debug_mode() == 16)
 		hipLaunchKernelGGL((k_render_forward<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
 		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr,
 		                   (const float*)nullptr, (float*)nullptr);
 	else
+#endif
 		hipLaunchKernelGGL((k_render_forward_walk<3>), dim3(p.T, 1), dim3(FR_THREADS), 0, s, p, features, 0,
 		                   (float*)((char*)image_ws + L.final_T), (uint32_t*)((char*)image_ws + L.n_contrib), out_features, (float*)nullptr,
 		                   (const float*)nullptr, (float*)nullptr);
@@ -5776,12 +5838,15 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	// (the pair keeps the two-pass tile kernel: with fourteen accumulators per candidate the walk form measured 0.83 against
 	// 0.79 ms at 2M Gaussians / 512 x 512 -- the single image gains, 0.49 against 0.59; FR_DEBUG_MODE=18 forces the walk form)
 	const bool pair_walk = fr_debug_mode() == 18;
+#ifdef FR_AB
 	if (pair_walk)
 	{
 		hipLaunchKernelGGL((k_backward_lin_walk<true>), dim3(p.T), block, 0, s, p, b);
 		if ((rc = fr_check_launch("k_backward_lin_walk<pair>"))) return rc;
 	}
-	else hipLaunchKernelGGL((k_backward_lin_tile<true>), dim3(p.T), block, 0, s, p, b, fallback);
+	else
+#endif
+	hipLaunchKernelGGL((k_backward_lin_tile<true>), dim3(p.T), block, 0, s, p, b, fallback);
 	if ((rc = fr_check_launch("k_backward_lin_tile<pair>"))) return rc;
 	// (two-pass kernel only) tiles whose lists do not fit the LDS index: the scan kernel, once per image
 	for (int pass = 0; pass < 2 && !pair_walk; pass++)
@@ -5810,11 +5875,13 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 //   9  the second-generation two-pass kernels instead of k_fisher_tile_v3 / _v3h
 //   2-7, 10-12 in a -DFR_LOOPSTATS build: loop-trip counters and s_memtime shares (tools/loopstats.py)
 // FR_GV / FR_VC (read once as well): Gaussians per thread / views per workgroup of k_preprocess_views.
+#ifdef FR_AB
 static int fr_debug_mode()
 {
-	static const int mode = [] { const char* dm = getenv("FR_DEBUG_MODE"); return dm ? atoi(dm) : 0; }();
+	static const int mode = fr_env_int("FR_DEBUG_MODE");
 	return mode;
 }
+#endif
 
 #define FR_MAX_GROUPS 4              // view groups of one fr_fisher_views call (fr_pick_groups)
 struct FrFisherLayout {
@@ -5890,9 +5957,12 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 	}
 	// FR_DEBUG_MODE=8: 8 x 8 pixel blocks per wave instead of 16 x 4 strips (A/B runs; measured 5 % slower on MI355X);
 	// FR_DEBUG_MODE=24: the rolling two-chunk window (k_fisher_tile_v3w: 24 % fewer walk iterations, 8 % slower -- see there)
+#ifdef FR_AB
 	if (f.debug_mode == 8) hipLaunchKernelGGL((k_fisher_tile_v3<8, 8>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	else if (f.debug_mode == 24) hipLaunchKernelGGL(k_fisher_tile_v3w, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f);
-	else if (f.key_shift) hipLaunchKernelGGL((k_fisher_tile_v3<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	else
+#endif
+	if (f.key_shift) hipLaunchKernelGGL((k_fisher_tile_v3<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	else hipLaunchKernelGGL((k_fisher_tile_v3<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	if (g_prof_on)
 	{
@@ -6067,6 +6137,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	// compact records with the multi-view front end (the same condition fr_bin_pipeline uses for it); FR_DEBUG_MODE=19: dense (A/B runs)
 	const bool compact = (v3 || v3h || v3g) && multi_fe && f.debug_mode != 19;
 	if (!compact) p.tile_cap = 0;                   // (fixed key segments are filled by the compact-record front end only)
+	else (void)fr_plan_views_c(p.T, fr_pick_VC(p.T), p.tile_cap);      // ... and only while their LDS cursors fit (decided HERE, before the stride)
 	// float4 per record: the general out_H forms 13 / 7, the score form 5 with fixed key segments (80 bytes: FrRecStride), else 6
 	const int rstride = v3g ? (fc->columns == 11 ? 13 : 7) : ((v3 && p.tile_cap) ? 5 : 6);
 	plan.ra.comp = compact ? (float4*)(ws + L.recq) : nullptr;

@@ -104,6 +104,35 @@ def test_product_never_imports_oracle():
                 assert "liboracle" not in txt and "fisher_oracle" not in txt.replace("oracle/fisher_oracle.c", ""), (d, f)
 
 
+def test_product_library_is_not_the_experiment_rig(lib):
+    """The library build() produces reads NO environment variable (no getenv import) and holds only kernels a default call can reach:
+    the A/B generations (rolling-window walk, 8 x 8 pixel blocks, the 25-leaf two-pass kernel, round 1's compositing and sort
+    forms, the parking projection kernels) exist in -DFR_AB builds only (tools/build_variant.sh -> tools/_build/)."""
+    import subprocess
+    import sys
+    from fisher_rast import _lib
+    so = _lib.SO_PATH
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, "the product library must not read the environment"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj
+    names = set()
+    for co in codeobj._code_objects(open(so, "rb").read()):
+        names |= set(codeobj._functions(co))
+    assert any("k_fisher_tile_v3ILi16ELi4ELb1E" in n for n in names)            # the dominant kernel is there
+    for banned in ("k_fisher_tile_v3w", "k_fisher_tile_v3ILi8ELi8E", "k_fisher_tile_v2ILi25E", "k_pack_staticILi25E", "k_render_forwardILi",
+                   "k_backward_lin_tileILb0E", "k_backward_lin_walkILb1E", "k_preprocess_viewsILi4E", "k_preprocess_viewsILin4E",
+                   "k_preprocess_viewsILi11E"):
+        assert not any(banned in n for n in names), banned
+    src = open(os.path.join(ROOT, "fisher-nerf-customized_amd", "csrc", "fisher_rast.hip")).read()
+    outside = re.sub(r"#ifdef FR_AB\b.*?#e(?:ndif|lse)", "", src, flags=re.S)
+    assert "getenv" not in outside and "getenv" not in open(os.path.join(ROOT, "fisher-nerf-customized_amd", "csrc", "fisher_occ.hip")).read()
+    for py in ("ops.py", "_lib.py", "distributed.py", "path_eval.py"):
+        txt = open(os.path.join(ROOT, "fisher-nerf-customized_amd", "fisher_rast", py)).read()
+        for var in ("FR_DEBUG_MODE", "FR_STREAMS", "FR_TILE_CAPACITY", "FR_GROUPS", "FR_GV", "FR_VC"):
+            assert var not in txt, (py, var)
+
+
 def test_missing_library_fails_loudly(monkeypatch, lib):
     from fisher_rast import _lib
     monkeypatch.setattr(_lib, "_lib", None)

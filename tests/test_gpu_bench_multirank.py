@@ -76,15 +76,3 @@ def test_one_rank_process_group_runs_the_collectives_through_rccl(gpu, tmp_path)
     assert coll["collectives"]["backend"] == "nccl" and coll["collectives"]["world_size"] == 1
     assert "collectives" not in plain
     assert np.array_equal(s0, s1)
-
-
-def test_view_groups_give_the_same_scores(gpu, tmp_path):
-    """fr_fisher_views cut into view groups whose tile kernels run on a side stream under the next group's front end
-    (FR_GROUPS, off by default -- it measured slower): the scores must be bit-identical to the single launch."""
-    args = [sys.executable, "bench.py", "--gpus", "1", "--views", "64", "--steps", "2", "--warmup", "1", "--cpu-views", "0",
-            "--gaussians", "60000", "--size", "128", "--seed", "3", "--synthetic-hinv"]
-    one, s1 = _run(args, {"FR_GROUPS": "1"}, str(tmp_path / "g1.npy"))
-    two, s2 = _run(args, {"FR_GROUPS": "2"}, str(tmp_path / "g2.npy"))
-    four, s4 = _run(args, {"FR_GROUPS": "4"}, str(tmp_path / "g4.npy"))
-    assert one["roofline"]["launches_per_step"] == 1 and two["roofline"]["launches_per_step"] == 2 and four["roofline"]["launches_per_step"] == 4
-    assert s1.shape == (64,) and np.array_equal(s1, s2) and np.array_equal(s1, s4)

@@ -1,6 +1,6 @@
 """tools/outh11_bench.py (GPU box): the out_H modes of GaussianObjectSLAM at the bench size -- 11 columns, constant gradient
 (compute_Hessian / compute_H_train) and per-view gradient images (POp-GS probes) -- ms per call, front end included.
-FR_DEBUG_MODE=22 keeps round 2's two-pass kernel (k_fisher_tile_v2<11>) for A/B runs."""
+(-DFR_AB rig builds only, FISHER_RAST_SO=tools/_build/ab_rig.so) FR_DEBUG_MODE=22 keeps round 2's two-pass kernel (k_fisher_tile_v2<11>) for A/B runs."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "fisher-nerf-customized_amd")]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """out_H modes of fr_fisher_views on the benchmark scene: H_train over 16 keyframes (accumulated), 64 views with a diagonal
-per view, and one view.  FR_DEBUG_MODE=9 in the environment keeps the second-generation two-pass kernel (A/B)."""
+per view, and one view.  (-DFR_AB rig builds only, FISHER_RAST_SO=tools/_build/ab_rig.so) FR_DEBUG_MODE=9 in the environment keeps the second-generation two-pass kernel (A/B)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "fisher-nerf-customized_amd")):

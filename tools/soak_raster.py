@@ -58,7 +58,11 @@ def main():
     outs = {}
     for mode in ("0", "16", "17"):
         out = f"/tmp/soak_raster_{mode}.npz"
-        env = dict(os.environ, FR_DEBUG_MODE=mode)
+        # (modes 16 / 17 exist in the -DFR_AB rig only: tools/build_variant.sh rig)
+        rig = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "ab_rig.so")
+        if not os.path.exists(rig):
+            subprocess.check_call(["bash", os.path.join(os.path.dirname(os.path.abspath(__file__)), "build_variant.sh"), "rig"])
+        env = dict(os.environ, FR_DEBUG_MODE=mode, FISHER_RAST_SO=rig)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "dump", out, str(rounds), str(seed)], env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = dict(np.load(out))
