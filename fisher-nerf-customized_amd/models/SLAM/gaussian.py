@@ -30,49 +30,49 @@ from models.SLAM.utils.slam_helpers import (transformed_params2rendervar, transf
 from models.SLAM.utils.slam_external import update_seen_and_radius
 
 
+def _loss_pixel_mask(depth_sil, gt_depth, sil_thres, reject_outliers, need_presence):
+    """Pixels that enter the tracking / mapping loss, from the depth / silhouette / depth^2 render `depth_sil` [3,H,W] -- the rule of
+    the reference's get_loss (models/SLAM/gaussian.py:212-233) as one conjunction: a measured depth; with `reject_outliers` an
+    absolute depth error below ten times its median (taken over the whole frame: the zeros of unmeasured pixels count, as they do
+    there); no NaN in the rendered depth nor in its variance proxy E[z^2] - E[z]^2; with `need_presence` a silhouette above the
+    threshold.  Returns (rendered depth [1,H,W], boolean mask [1,H,W])."""
+    rendered = depth_sil[0:1]
+    keep = gt_depth > 0
+    if reject_outliers:
+        err = (gt_depth - rendered).abs() * keep
+        keep = keep & (err < 10 * err.median())
+    keep = keep & ~(torch.isnan(rendered) | torch.isnan(depth_sil[2:3] - rendered ** 2))
+    if need_presence:
+        keep = keep & (depth_sil[1] > sil_thres)
+    return rendered, keep.detach()
+
+
 def make_get_loss(transform_to_frame, calc_loss):
     """Drop-in for the module-level `get_loss` of the reference (models/SLAM/gaussian.py:184-297): same signature, same return
     `(loss, variables, weighted_losses)`.  What changes: the two rasteriser calls of 205-211 (RGB, then depth / silhouette /
     depth^2 on the same Gaussians) are ONE projection / binning / sort with two compositing passes and one fused backward
     (`render_rgb_depth_sil` -> fr_forward_pair / fr_backward_pair), and the `seen` / `max_2D_radius` update of 289-291 is one
-    kernel pass (fr_densify_stats).  The masks and the loss terms are the reference's own `calc_loss` and the pose / point
-    transform its own `transform_to_frame` (models/SLAM/utils/slam_helpers.py:23-44, 282-317), handed in by the caller --
-    `FisherOps.install` takes them from the reference module it patches.  The matplotlib dump of 240-284 is not reproduced
-    (visualize_tracking_loss is accepted and ignored)."""
+    kernel pass (fr_densify_stats).  The loss terms are the reference's own `calc_loss` and the pose / point transform its own
+    `transform_to_frame` (models/SLAM/utils/slam_helpers.py:23-44, 282-317), handed in by the caller; the pixel mask is
+    `_loss_pixel_mask`.  The matplotlib dump of 240-284 is not reproduced (visualize_tracking_loss is accepted and ignored).
+    Opt-in: `FisherOps.install(cls, patch_get_loss=True)` puts it into the reference module."""
     @torch.enable_grad()
     def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss,
                  sil_thres, use_l1, ignore_outlier_depth_loss, tracking=False,
                  mapping=False, do_ba=False, plot_dir=None, visualize_tracking_loss=False, tracking_iteration=None):
-        if tracking:
-            transformed_pts = transform_to_frame(params, iter_time_idx, gaussians_grad=False, camera_grad=True)
-        elif mapping:
-            transformed_pts = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=False)
-        else:
+        if not (tracking or mapping):
             raise ValueError("get_loss: one of tracking / mapping must be set")     # (the reference fails with a NameError here)
-        im, radius, depth_sil, rendervar = render_rgb_depth_sil(params, curr_data['cam'], curr_data['w2c'], transformed_pts)
-        variables['means2D'] = rendervar['means2D']      # gradient only accumulates from the colour render (gaussian.py:207)
-        depth = depth_sil[0, :, :].unsqueeze(0)
-        silhouette = depth_sil[1, :, :]
-        presence_sil_mask = (silhouette > sil_thres)
-        depth_sq = depth_sil[2, :, :].unsqueeze(0)
-        uncertainty = (depth_sq - depth ** 2).detach()
-        nan_mask = (~torch.isnan(depth)) & (~torch.isnan(uncertainty))
-        if ignore_outlier_depth_loss:
-            depth_error = torch.abs(curr_data['depth'] - depth) * (curr_data['depth'] > 0)
-            mask = (depth_error < 10 * depth_error.median())
-            mask = mask & (curr_data['depth'] > 0)
-        else:
-            mask = (curr_data['depth'] > 0)
-        mask = mask & nan_mask
-        if tracking and use_sil_for_loss:
-            mask = mask & presence_sil_mask
-        color_mask = torch.tile(mask, (3, 1, 1)).detach()
-        losses = calc_loss(curr_data, im, depth, mask, color_mask, use_l1, use_sil_for_loss, ignore_outlier_depth_loss, tracking)
-        weighted_losses = {k: v * loss_weights[k] for k, v in losses.items()}
-        loss = sum(weighted_losses.values())
+        # tracking: only the camera pose takes a gradient; mapping: only the Gaussians (gaussian.py:189-199)
+        pts = transform_to_frame(params, iter_time_idx, gaussians_grad=not tracking, camera_grad=bool(tracking))
+        im, radius, depth_sil, rendervar = render_rgb_depth_sil(params, curr_data['cam'], curr_data['w2c'], pts)
+        variables['means2D'] = rendervar['means2D']      # densification reads the colour render's screen-space gradient (gaussian.py:207)
+        depth, mask = _loss_pixel_mask(depth_sil, curr_data['depth'], sil_thres, ignore_outlier_depth_loss, tracking and use_sil_for_loss)
+        terms = calc_loss(curr_data, im, depth, mask, mask.repeat(3, 1, 1), use_l1, use_sil_for_loss, ignore_outlier_depth_loss, tracking)
+        weighted = {name: value * loss_weights[name] for name, value in terms.items()}
+        total = sum(weighted.values())
         update_seen_and_radius(variables, radius)        # variables['seen'], variables['max_2D_radius'] (gaussian.py:289-291)
-        weighted_losses['loss'] = loss
-        return loss, variables, weighted_losses
+        weighted['loss'] = total
+        return total, variables, weighted
     return get_loss
 
 
@@ -211,8 +211,10 @@ class FisherOps:
         return scorer.run(self._as_w2c(w2cs), H_inv=H_inv_per_view, H_inv_per_view=True)["scores"]
 
     @classmethod
-    def install(cls, target_cls):
-        """Graft the accelerated methods onto the reference's class."""
+    def install(cls, target_cls, patch_get_loss=False):
+        """Graft the accelerated methods onto the reference's class.  `patch_get_loss=True` also replaces the
+        module-level `get_loss` of the module `target_cls` lives in by the fused-render form (`make_get_loss`); off by default --
+        a caller that only wants the Fisher scorer keeps the reference's training step untouched."""
         for name in ("_device", "_as_w2c", "_stack_poses", "_scorer", "_scorer_key", "_PARAM_KEYS", "compute_Hessian", "compute_H_train",
                      "pose_eval", "path_scores"):
             setattr(target_cls, name, getattr(cls, name))
@@ -220,7 +222,7 @@ class FisherOps:
         # transform_to_frame / calc_loss: one fused render pair instead of two rasteriser calls
         import sys
         mod = sys.modules.get(target_cls.__module__)
-        if mod is not None and all(hasattr(mod, n) for n in ("get_loss", "transform_to_frame", "calc_loss")):
+        if patch_get_loss and mod is not None and all(hasattr(mod, n) for n in ("get_loss", "transform_to_frame", "calc_loss")):
             mod.get_loss = make_get_loss(mod.transform_to_frame, mod.calc_loss)
         if not hasattr(target_cls, "FISHER_COLUMNS"):
             target_cls.FISHER_COLUMNS = cls.FISHER_COLUMNS

@@ -228,3 +228,51 @@ def test_install_grafts_methods_onto_reference_like_classes():
     OccupancyOps.install(RefPlanner)
     assert all(callable(getattr(RefPlanner, n)) for n in ("update_occ_map", "build_connected_freespace", "build_frontiers", "generate_candidate",
                                                                    "generate_candidate_object", "generate_candidate_in_freespace", "sample_random_candidate"))
+
+
+def test_get_loss_graft_is_opt_in_and_the_pixel_mask_follows_the_reference_rule():
+    """`install` leaves the module-level get_loss of the module it patches alone unless asked (patch_get_loss=True); the loss
+    mask (`_loss_pixel_mask`) equals the rule of the reference's get_loss (gaussian.py:212-233), restated here step by step."""
+    import types
+    import sys
+    from models.SLAM import gaussian as G
+    mod = types.ModuleType("fake_ref_gaussian")
+    mod.get_loss = lambda *a, **k: "reference"
+    mod.transform_to_frame = lambda *a, **k: None
+    mod.calc_loss = lambda *a, **k: {}
+    sys.modules[mod.__name__] = mod
+    try:
+        cls = type("RefSLAM", (), {"__module__": mod.__name__})
+        G.FisherOps.install(cls)
+        assert mod.get_loss() == "reference"
+        G.FisherOps.install(cls, patch_get_loss=True)
+        assert mod.get_loss.__name__ == "get_loss" and mod.get_loss.__module__ == G.__name__
+    finally:
+        del sys.modules[mod.__name__]
+    g = torch.Generator().manual_seed(4)
+    Hh, Ww = 24, 32
+    gt = torch.rand((1, Hh, Ww), generator=g) * 4
+    gt[0, :3] = 0                                              # unmeasured rows
+    ds = torch.rand((3, Hh, Ww), generator=g) * 4
+    ds[0] = gt[0] + 0.05 * torch.randn((Hh, Ww), generator=g)
+    ds[0, 10, 10] += 9.0                                       # an outlier
+    ds[0, 5, 5] = float("nan")
+    ds[2, 6, 6] = float("nan")
+    for outl in (False, True):
+        for pres in (False, True):
+            depth, mask = G._loss_pixel_mask(ds, gt, 0.5, outl, pres)
+            d = ds[0].unsqueeze(0)
+            unc = ds[2].unsqueeze(0) - d ** 2
+            nanm = (~torch.isnan(d)) & (~torch.isnan(unc))
+            if outl:
+                err = torch.abs(gt - d) * (gt > 0)
+                m = (err < 10 * err.median()) & (gt > 0)
+            else:
+                m = gt > 0
+            m = m & nanm
+            if pres:
+                m = m & (ds[1] > 0.5)
+            assert mask.shape == (1, Hh, Ww) and mask.dtype == torch.bool and torch.equal(mask, m)
+            assert torch.equal(torch.nan_to_num(depth), torch.nan_to_num(d))
+            assert not bool(mask[0, 5, 5]) and not bool(mask[0, 6, 6]) and not bool(mask[0, 0, 0])
+            assert bool(mask[0, 10, 10]) == (not outl and (not pres or bool(ds[1, 10, 10] > 0.5)))

@@ -107,7 +107,8 @@ def test_backward_parity(runs, oracle, gpu, case, power):
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations")
     if power == 2:
         # the arbiter (the oracle's statements in binary64 on the same contributor sets): a Gaussian whose reference chain is
-        # itself off by r > 0 in binary32 (near-plane giants of `general`: up to 1.2e-4) gets (1e-4 + 2 r) instead of 1e-4
+        # itself off by r > 0 in binary32 (near-plane giants of `general`: up to 1.2e-4) gets (1e-4 + min(1.25 r, 0.3)) instead of 1e-4
+        # (tools/arbiter_diag.py measured a need of 0.95 r at most)
         w64 = oracle.rasterize_forward(cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"],
                                        rotations=sc["rotations"], decisions=want)
         ga = oracle.rasterize_backward(cam, w64, dL, power)
@@ -117,10 +118,11 @@ def test_backward_parity(runs, oracle, gpu, case, power):
             o, a = gw[n].astype(np.float64).reshape(gw[n].shape[0], -1), ga[n].reshape(gw[n].shape[0], -1)
             big = np.abs(a) > 1e-7 * np.abs(a).max()
             r = np.where(big, np.abs(o - a) / np.maximum(np.abs(a), 1e-300), 0.0).max(axis=1, keepdims=True)
-            tol = (1e-4 + 2.0 * r) * np.abs(o) + 1e-7 * np.abs(o).max()
+            tol = (1e-4 + np.minimum(1.25 * r, 0.3)) * np.abs(o) + 1e-7 * np.abs(o).max()
             bad = np.abs(gg[n].astype(np.float64).reshape(o.shape) - o) > tol
             assert not bad.any(), (f"{case}/{n}", int(bad.sum()), float((np.abs(gg[n].reshape(o.shape) - o) / np.maximum(tol, 1e-300)).max()))
             assert (r > 2e-5).mean() < 0.02
+            print(f"[{case}/{n}] widened Gaussians: {int((r > 2e-5).sum())} of {r.shape[0]}, largest r {float(r.max()):.2e}")
         else:
             assert_close(gg[n], gw[n], 1e-4, f"{case}/{n}", atol_frac=2e-5)
     assert gg["dL_dsh"].shape == (sc["means3D"].shape[0], 0, 3)

@@ -134,15 +134,26 @@ def family(gpu, oracle):
 # (tools/arbiter_diag.py): 0.95 at most, 4 and 11 columns alike -- every out_H mode runs on records in the u = -conic d basis now
 # (k_fisher_tile_v3h, k_fisher_tile_v3g); round 2's two-pass kernel for 11 columns (the reference's own (dx, dy) chain with a
 # different rounding sequence) needed 5.1.
-K_DEV = {4: 2.0, 11: 2.0}
+K_DEV = {4: 1.25, 11: 1.25}
+# ... and the widening is capped: the worst Gaussian the arbiter has found is off by 0.22 (11 columns); a chain that loses more than
+# that gets no further allowance, so a kernel regression on ill-conditioned splats still fails
+WIDEN_CAP = 0.3
 
 
 def _entry_tolerance(o, a, C):
-    """[P, C] tolerance: (1e-4 + K r_G) |o| + 1e-7 max|o|, r_G = the largest relative deviation of the binary32 oracle `o` from the
+    """[P, C] tolerance: (1e-4 + min(K r_G, cap)) |o| + 1e-7 max|o|, r_G = the largest relative deviation of the binary32 oracle `o` from the
     arbiter `a` over the Gaussian's columns (entries below 1e-7 of the largest are not rated)."""
     o64, big = o.astype(np.float64), np.abs(a) > 1e-7 * np.abs(a).max()
     r = np.where(big, np.abs(o64 - a) / np.maximum(np.abs(a), 1e-300), 0.0).max(axis=1, keepdims=True)
-    return (1e-4 + K_DEV[C] * r) * np.abs(o64) + 1e-7 * np.abs(o64).max(), r
+    return (1e-4 + np.minimum(K_DEV[C] * r, WIDEN_CAP)) * np.abs(o64) + 1e-7 * np.abs(o64).max(), r
+
+
+def _k_needed(got, o, a, C):
+    """the multiple of r_G the worst entry of `got` actually needed beyond the flat 1e-4 (reported, so that K_DEV can be judged)"""
+    r = _entry_tolerance(o, a, C)[1]
+    o64 = o.astype(np.float64)
+    excess = (np.abs(got - o64) - 1e-7 * np.abs(o64).max()) / np.maximum(np.abs(o64), 1e-300) - 1e-4
+    return float(np.where((excess > 0) & (r > 0), excess / np.maximum(r, 1e-300), 0.0).max())
 
 
 @pytest.mark.parametrize("columns", [4, 11])
@@ -177,6 +188,10 @@ def test_scorer_modes_on_adversarial_families(family, gpu, case, columns):
     # Gaussian) pairs (measured on the CPU: crowded_tile 1.2-1.5 % -- deep contributors behind thousands of splats --, border
     # 0.5-1.0 %, ragged 0.5-0.7 %, thresholds 0.08 %, general 0.007 %, ties / opaque none)
     assert n_wide <= 0.02 * V * P, (case, n_wide)
+    r_max = max(float(_entry_tolerance(cur_o[v], cur_a[v], C)[1].max()) for v in range(V))
+    need = max(_k_needed(cur[v].cpu().numpy().astype(np.float64), cur_o[v], cur_a[v], C) for v in range(V))
+    print(f"[{case}-{C}] widened (view, Gaussian) pairs: {n_wide} of {V * P} ({100.0 * n_wide / (V * P):.3f} %), largest r_G {r_max:.2e}, "
+          f"K needed {max(need, 0.0):.2f} of K_DEV {K_DEV[C]}")
     Ht = torch.zeros((P, C), device=gpu)
     sc.run(w2c[1:], out_H=Ht)
     bad = np.abs(Ht.cpu().numpy().astype(np.float64) - H_train_o) > np.sum(tols[1:], axis=0)
