@@ -3382,6 +3382,247 @@ void k_fisher_tile_v3(FrParams p, FrFisherArgs f, const float4* __restrict__ rec
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_fisher_tile_v4: k_fisher_tile_v3<16, 4, MK> with ROLLING HALVES.  In k_fisher_tile_v3 the wave re-converges after every chunk
+// of 64 candidates, so a chunk costs as many walk iterations as its busiest pixel-lane has candidates: 44 % of the lane slots do
+// work (profiles/r03_m_loopstats.txt).  Here the 64 record slots / 64 mask bits are two halves of 32: the low word of a pixel's
+// mask is the OLDER half, the high word the younger one; a lane that has walked its bits of the older half goes straight on to the
+// younger half's (ffs over the 64 bits gives exactly that order), and the wave only re-converges when NO lane has a bit of the older
+// half left -- then the halves swap roles (mask >>= 32, the slot base flips: slot = bit ^ base) and the freed 32 slots take the next
+// 32 candidates.  A lane can thus run up to a whole half ahead of the slowest one at no cost per iteration but one v_xor (round 3's
+// window kernel, k_fisher_tile_v3w, paid 8 vector instructions and two scalar branches per iteration for the same freedom).
+// The set-up of a half uses all 64 lanes: lane = 32 h + c parks its part of candidate c's record (h = 0: three float4, h = 1: two),
+// rasterises rows 2h, 2h+1 of the candidate's footprint into a 32-bit word, and a 32 x 32 bit transpose inside each half-wave (five
+// DPP / permlane16 rounds on 32-bit words; the 64 x 64 one takes six on 64-bit words) hands every pixel-lane its 32 candidate bits.
+// Pairs, their order per pixel and their arithmetic are k_fisher_tile_v3's: the scores are bit-identical.
+// Fixed key segments only (the keys carry the strip bits; 80-byte records at stride 5).
+template <int SFT>
+__device__ __forceinline__ uint32_t fr_transpose_round32(uint32_t x, int lane)
+{
+	constexpr uint32_t m = SFT == 16 ? 0x0000FFFFu : SFT == 8 ? 0x00FF00FFu : SFT == 4 ? 0x0F0F0F0Fu : SFT == 2 ? 0x33333333u : 0x55555555u;
+	uint32_t other;
+	if constexpr (SFT == 1) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+	else if constexpr (SFT == 2) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+	else if constexpr (SFT == 4) other = (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)x, 0x1B, 0xf, 0xf, false), 0x141, 0xf, 0xf, false);   // (i ^ 3) ^ 7 = i ^ 4
+	else if constexpr (SFT == 8) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, false);    // row_ror:8
+	else
+	{
+		const auto t = __builtin_amdgcn_permlane16_swap(x, x, false, false);     // [0]: the lower row's word on both lanes of a pair, [1]: the upper's
+		other = (lane & 16) ? t[0] : t[1];
+	}
+	return (lane & SFT) ? ((x & ~m) | ((other & ~m) >> SFT)) : ((x & m) | ((other & m) << SFT));
+}
+// 32 x 32 bit-matrix transpose inside each half of the wave: lane 32 h + i holds row i in, row i of the transpose out
+__device__ __forceinline__ uint32_t fr_half_transpose32(uint32_t x, int lane)
+{
+	x = fr_transpose_round32<16>(x, lane);
+	x = fr_transpose_round32<8>(x, lane);
+	x = fr_transpose_round32<4>(x, lane);
+	x = fr_transpose_round32<2>(x, lane);
+	x = fr_transpose_round32<1>(x, lane);
+	return x;
+}
+// Two rows (y0, y0 + 1) of a candidate's footprint over the strip's 16 columns: bit 16 r + column.  The rule of k_fisher_tile_v3's
+// chunk step for records without extents (the conic's quadratic, widened by 1 % + 0.01 px: a superset of the exact pair test).
+__device__ __forceinline__ uint32_t fr_footprint_rows2(const float4& a, const float4& b4, float y0, float tile_x0)
+{
+	const float ax = a.x, ay = a.y;
+	const float acx = -2.0f * b4.x, acy = -b4.y, acz = -2.0f * b4.z;
+	const float athr = -(5.541263545158426f + 0.6931471805599453f * a.w) - 0.01f;      // fr_power_threshold: alpha < 1/255 below it
+	const bool quad_ok = acx > 0.f && athr <= 0.f;
+	const float racx = __builtin_amdgcn_rcpf(acx);
+	uint32_t em = 0u;
+#pragma unroll
+	for (unsigned r = 0; r < 2u; r++)
+	{
+		const float dy = ay - (y0 + (float)r);
+		float lo = -1e30f, hi2 = 1e30f;
+		bool any_px = fabsf(dy) <= 1e30f;
+		if (quad_ok)
+		{
+			const float hb = acy * dy;
+			const float cq = acz * dy * dy + 2.0f * athr;
+			const float disc = hb * hb - acx * cq;
+			any_px = any_px && (disc >= 0.f);
+			const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * 1.01f + 0.01f * acx;
+			const float dlo = (-hb - sq) * racx, dhi = (-hb + sq) * racx;
+			lo = ax - dhi - 0.01f; hi2 = ax - dlo + 0.01f;
+		}
+		const float c0f = fmaxf(ceilf(lo) - tile_x0, 0.f), c1f = fminf(floorf(hi2) - tile_x0, 15.0f);
+		if (any_px && c0f <= c1f)
+		{
+			const unsigned c0 = (unsigned)c0f, c1 = (unsigned)c1f;
+			em |= (((2u << c1) - 1u) & ~((1u << c0) - 1u)) << (16u * r);
+		}
+	}
+	return em;
+}
+
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 7)))
+void k_fisher_tile_v4(FrParams p, FrFisherArgs f)
+{
+	__shared__ uint32_t s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][64][FR_ENT3_F4];
+	__shared__ float s_red[4];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	uint32_t tile; int v;
+	fr_tile_of_block(p, tile, v);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t bx0 = tx * FR_BLOCK_X, by0 = ty * FR_BLOCK_Y + (uint32_t)wave * 4u;
+	const uint32_t pxx = bx0 + (uint32_t)(lane & 15), pxy = by0 + (uint32_t)(lane >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const size_t vt = (size_t)v * p.T + tile;
+	const uint32_t n = p.tile_cnt[vt];
+	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const float4* rec = f.recA + (size_t)v * f.ab_view;          // 80-byte records: {x, y, k3, log2 o} {-cx/2, -cy, -cz/2, cg} + 12 coefficients
+	uint32_t* wq = s_q[wave];
+	float4 (*ent)[FR_ENT3_F4] = s_ent[wave];
+	const uint32_t ent_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&s_ent[wave][0][0];
+	uint32_t ent_lds_v;
+	asm volatile("v_mov_b32 %0, %1" : "=v"(ent_lds_v) : "s"(ent_lds));
+	const int hc = lane & 31;                                      // set-up role: candidate of the half ...
+	const int hh = lane >> 5;                                      // ... and which part of it (rows 2 hh, 2 hh + 1; float4 0-2 or 3-4)
+	const float rows_y0 = (float)by0 + 2.0f * (float)hh;
+	const float tile_x0 = (float)bx0;
+	float T = 1.0f, Cg = 0.f, Xt = 0.f, sA = 0.f, sB = 0.f, sD = 0.f;
+	bool done = !inside;
+	uint32_t qh = 0, qn = 0;
+#ifdef FR_LOOPSTATS
+	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0;
+	long long dbg_t0 = 0, dbg_ts = 0, dbg_tc = 0, dbg_tw = 0;
+#define FR_V4_STAMP(acc) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); acc += t_ - dbg_t0; dbg_t0 = t_; }
+#else
+#define FR_V4_STAMP(acc)
+#endif
+	// ---- key stream (k_fisher_tile_v3's, MK form): keep the keys that carry this wave's strip bit, append their slots to the ring
+	uint32_t id1 = 0, id2 = 0;
+	if ((uint32_t)lane < n) id1 = (uint32_t)FR_LDK(gk + lane);
+	if (64u + lane < n) id2 = (uint32_t)FR_LDK(gk + 64 + lane);
+	uint32_t base = 0;
+	auto stream_fill = [&]() {
+		while (qn < 32u && base < n)
+		{
+			const uint32_t idc = id1;
+			id1 = id2;
+			if (base + 128 + lane < n) id2 = (uint32_t)FR_LDK(gk + base + 128 + lane);
+			const bool ov = (base + lane < n) && ((idc >> wave) & 1u);
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = idc >> 4;
+			qn += (uint32_t)__popcll(om);
+			base += 64;
+		}
+	};
+	// ---- the next half's records, gathered into registers one half ahead of their parking (two lanes per candidate)
+	float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga, g2 = ga, g3 = ga;
+	uint32_t pm = 0;
+	auto gather_next = [&]() {
+		pm = qn < 32u ? qn : 32u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if ((uint32_t)hc < pm)
+		{
+			const float4* r = rec + (size_t)FR_ENT3_F4 * wq[(qh + hc) & (FR_QCAP - 1)];
+			ga = r[0]; gb = r[1];
+			if (hh == 0) g2 = r[2];
+			else { g2 = r[3]; g3 = r[4]; }
+		}
+		qh = (qh + pm) & (FR_QCAP - 1); qn -= pm;
+	};
+#ifdef FR_LOOPSTATS
+	dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+	stream_fill();
+	gather_next();
+	FR_V4_STAMP(dbg_ts)
+	unsigned long long mask = 0ull;                  // low word: the older half's candidates of this pixel, high word: the younger half's
+	uint32_t base0 = 0;                              // slot of bit j = j ^ base0 (0 or 32, wave-uniform)
+	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	while (!all_done)
+	{
+		// ---- set-up: park the gathered half in the younger half's slots, rasterise two footprint rows per lane
+		const uint32_t m = pm;
+		uint32_t em = 0u;
+		if ((uint32_t)hc < m)
+		{
+			float4* e = ent[(32u ^ base0) + (uint32_t)hc];
+			if (hh == 0) { e[0] = ga; e[1] = gb; e[2] = g2; }
+			else { e[3] = g2; e[4] = g3; }
+			em = fr_footprint_rows2(ga, gb, rows_y0, tile_x0);
+		}
+#ifdef FR_LOOPSTATS
+		dbg_chunks++; dbg_cand += (int)m;
+#endif
+		FR_V4_STAMP(dbg_tc)
+		stream_fill();
+		gather_next();
+		FR_V4_STAMP(dbg_ts)
+		uint32_t nm = fr_half_transpose32(em, lane);
+		if (done) nm = 0u;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		mask |= (unsigned long long)nm << 32;
+		if (m == 0u && __builtin_amdgcn_ballot_w64(mask != 0ull) == 0ull) break;     // nothing parked, nothing left to walk
+		FR_V4_STAMP(dbg_tc)
+		// ---- walk until no lane holds a bit of the older half
+		while (__builtin_amdgcn_ballot_w64((uint32_t)mask != 0u) != 0ull)
+		{
+#ifdef FR_LOOPSTATS
+			dbg_wsteps++;
+#endif
+			if (mask != 0ull)
+			{
+				const uint32_t j = (uint32_t)(__ffsll((long long)mask) - 1);
+				mask &= mask - 1ull;
+				FrWalkRec3 r;
+				{
+					const uint32_t addr = ent_lds_v + (j ^ base0) * (FR_ENT3_F4 * 16);
+					asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+					             "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\t"
+					             "s_waitcnt lgkmcnt(0)"
+					             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2) : "v"(addr) : "memory");
+				}
+#ifdef FR_LOOPSTATS
+				dbg_steps++;
+#endif
+				const FrWalkGeom g = fr_walk_geom(r, pfx, pfy);
+				const bool kill = fr_walk_update(g, g.ok, T, Cg, Xt, sA, sB, sD);
+#ifdef FR_LOOPSTATS
+				dbg_hits += (g.ok && !kill) ? 1 : 0;
+#endif
+				if (kill) { mask = 0ull; done = true; }
+			}
+		}
+		FR_V4_STAMP(dbg_tw)
+		// ---- the older half is finished by every lane: its slots are free, the younger half becomes the older one
+		mask >>= 32;
+		base0 ^= 32u;
+		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+	}
+	const float X = Cg + T * (p.bg[0] + p.bg[1] + p.bg[2]);
+	const float dlt = X - Xt;
+	float score = inside ? (sA + dlt * (dlt * sD - 2.0f * sB)) : 0.f;
+	float ws = wave_sum(score);
+#ifdef FR_LOOPSTATS
+	if (f.debug_mode >= 2)
+	{
+		if (f.debug_mode == 13) ws = (float)(base < n ? base : n);
+		else if (f.debug_mode == 14) ws = (float)n;
+		else if (f.debug_mode >= 10) ws = (float)((f.debug_mode == 10 ? dbg_ts : f.debug_mode == 11 ? dbg_tc : dbg_tw) >> 6);
+		else ws = f.debug_mode == 2 ? (float)dbg_cand : f.debug_mode == 3 ? (float)dbg_chunks : f.debug_mode == 4 ? (float)dbg_wsteps
+		        : f.debug_mode == 5 ? wave_sum((float)dbg_hits) : f.debug_mode == 7 ? (float)wave_max_i(dbg_steps) : wave_sum((float)dbg_steps);
+	}
+	else
+#endif
+	ws *= f.dL * f.dL;
+	if (lane == 0) s_red[wave] = ws;
+	__syncthreads();
+	if (tid == 0) f.tile_scores[vt] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+#undef FR_V4_STAMP
+
+// ---------------------------------------------------------------------------------------------------------
 // out_H mode of the third generation (no H_inv, constant upstream gradient, 4 columns: compute_Hessian / H_train of the
 // scene map): the per-Gaussian diagonal itself is wanted, so the pixel's X = Cg_final + T_final sum(bg) has to be known
 // before a pair can be squared.  Two front-to-back passes of the same wave over the same list:
@@ -5960,9 +6201,10 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 #ifdef FR_AB
 	if (f.debug_mode == 8) hipLaunchKernelGGL((k_fisher_tile_v3<8, 8>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	else if (f.debug_mode == 24) hipLaunchKernelGGL(k_fisher_tile_v3w, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f);
+	else if (f.key_shift && f.debug_mode == 31) hipLaunchKernelGGL((k_fisher_tile_v3<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);   // FR_DEBUG_MODE=31: the chunk-synchronous walk of round 3
 	else
 #endif
-	if (f.key_shift) hipLaunchKernelGGL((k_fisher_tile_v3<16, 4, true>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	if (f.key_shift) hipLaunchKernelGGL(k_fisher_tile_v4, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f);
 	else hipLaunchKernelGGL((k_fisher_tile_v3<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
 	if (g_prof_on)
 	{
