@@ -305,23 +305,23 @@ def valu_ceiling():
 
 
 def pmc_record(P, V, W, C):
-    """Hardware counters of the k_fisher_tile_v3 dispatches of ONE step, collected by tools/pmc_collect.sh (rocprofv3 --pmc, separate
-    passes) and folded by tools/pmc_summary.py into profiles/pmc_k_fisher_tile_v3.json.  The record carries the sha256 of the kernel's
+    """Hardware counters of the k_fisher_tile_v4 dispatches of ONE step, collected by tools/pmc_collect.sh (rocprofv3 --pmc, separate
+    passes) and folded by tools/pmc_summary.py into profiles/pmc_k_fisher_tile_v4.json.  The record carries the sha256 of the kernel's
     gfx950 machine code as it sat in the library the counters were taken on (tools/codeobj.py); it is used only when the library
     loaded NOW holds the same code -- recomputed here, so there is no stamp to maintain by hand."""
     from fisher_rast import _lib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import codeobj
-    f = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v3.json")
+    f = os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v4.json")
     if not os.path.exists(f):
         return None, {"file": None, "fresh": False, "why": "no PMC record committed"}
     pm = json.load(open(f))
-    now = codeobj.kernel_code_id(_lib.SO_PATH, "k_fisher_tile_v3I")
-    meta = {"file": "profiles/pmc_k_fisher_tile_v3.json", "commit": pm.get("commit"), "kernel_code_id": pm.get("kernel_code_id"),
+    now = codeobj.kernel_code_id(_lib.SO_PATH, "k_fisher_tile_v4")
+    meta = {"file": "profiles/pmc_k_fisher_tile_v4.json", "commit": pm.get("commit"), "kernel_code_id": pm.get("kernel_code_id"),
             "kernel_code_id_loaded": now, "fresh": True,
             "source": "cached: rocprofv3 --pmc passes of tools/pmc_collect.sh, not measured in this run"}
     if pm.get("kernel_code_id") is None or pm.get("kernel_code_id") != now:
-        meta.update(fresh=False, why="the loaded library's k_fisher_tile_v3 is not the code the counters were taken on")
+        meta.update(fresh=False, why="the loaded library's k_fisher_tile_v4 is not the code the counters were taken on")
     elif not (pm.get("gaussians") == P and pm.get("views") == V and pm.get("size") == W and pm.get("columns") == C):
         meta.update(fresh=False, why="counters were taken on another workload")
     return (pm if meta["fresh"] else None), meta
@@ -491,7 +491,7 @@ def main():
         # (radius rectangles), the front end lists a splat only in the tiles its alpha footprint reaches
         R = float(int(last["status"].cpu()[0]))
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        # algorithmic bytes of ONE k_fisher_tile_v3 launch: per tile instance the sorted key (8 B), the
+        # algorithmic bytes of ONE k_fisher_tile_v4 launch: per tile instance the sorted key (8 B), the
         # 32-byte {recA, recB} record and the 52 used bytes of the recQ record, each moved once; plus one partial score per (view, tile)
         per_instance = BYTES_PER_TILE_INSTANCE_FIXED if scorer.tile_capacity > 0 else BYTES_PER_TILE_INSTANCE
         kern_bytes = (R * per_instance + 4.0 * V * T) / launches_per_step
@@ -535,7 +535,7 @@ def main():
             "build": {"build_id": lib.fr_build_id().decode(), "so_path": os.path.relpath(_lib.SO_PATH, ROOT)},
             # `bound`: the contract's HBM roofline (algorithmic bytes over time against 8 TB/s) is what achieved / peak / frac hold;
             # what actually limits the kernel is its per-pair VALU work: `binding` and the `valu` block (frac of the calibrated ceiling)
-            "roofline": {"bound": "hbm", "binding": "valu", "kernel": "k_fisher_tile_v3", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "binding": "valu", "kernel": "k_fisher_tile_v4" if scorer.tile_capacity > 0 else "k_fisher_tile_v3", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
                          "bytes_per_tile_instance": per_instance, "launches_per_step": launches_per_step,

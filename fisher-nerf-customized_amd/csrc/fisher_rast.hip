@@ -3490,7 +3490,7 @@ void k_fisher_tile_v4(FrParams p, FrFisherArgs f)
 	bool done = !inside;
 	uint32_t qh = 0, qn = 0;
 #ifdef FR_LOOPSTATS
-	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0;
+	int dbg_cand = 0, dbg_chunks = 0, dbg_steps = 0, dbg_hits = 0, dbg_wsteps = 0, dbg_cs = 0;
 	long long dbg_t0 = 0, dbg_ts = 0, dbg_tc = 0, dbg_tw = 0;
 #define FR_V4_STAMP(acc) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); acc += t_ - dbg_t0; dbg_t0 = t_; }
 #else
@@ -3566,34 +3566,35 @@ void k_fisher_tile_v4(FrParams p, FrFisherArgs f)
 		if (m == 0u && __builtin_amdgcn_ballot_w64(mask != 0ull) == 0ull) break;     // nothing parked, nothing left to walk
 		FR_V4_STAMP(dbg_tc)
 		// ---- walk until no lane holds a bit of the older half
-		while (__builtin_amdgcn_ballot_w64((uint32_t)mask != 0u) != 0ull)
+		// (a divergent loop: a lane leaves when it has no bit left in either half -- it cannot get one before the next set-up -- and the
+		// lanes still inside leave together once none of them holds a bit of the older half: the vote only needs the active lanes)
+		while (mask != 0ull)
 		{
-#ifdef FR_LOOPSTATS
-			dbg_wsteps++;
-#endif
-			if (mask != 0ull)
+			if (__builtin_amdgcn_ballot_w64((uint32_t)mask != 0u) == 0ull) break;
+			const uint32_t j = (uint32_t)(__ffsll((long long)mask) - 1);
+			mask &= mask - 1ull;
+			FrWalkRec3 r;
 			{
-				const uint32_t j = (uint32_t)(__ffsll((long long)mask) - 1);
-				mask &= mask - 1ull;
-				FrWalkRec3 r;
-				{
-					const uint32_t addr = ent_lds_v + (j ^ base0) * (FR_ENT3_F4 * 16);
-					asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
-					             "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\t"
-					             "s_waitcnt lgkmcnt(0)"
-					             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2) : "v"(addr) : "memory");
-				}
-#ifdef FR_LOOPSTATS
-				dbg_steps++;
-#endif
-				const FrWalkGeom g = fr_walk_geom(r, pfx, pfy);
-				const bool kill = fr_walk_update(g, g.ok, T, Cg, Xt, sA, sB, sD);
-#ifdef FR_LOOPSTATS
-				dbg_hits += (g.ok && !kill) ? 1 : 0;
-#endif
-				if (kill) { mask = 0ull; done = true; }
+				uint32_t addr;                                     // (hipcc picks the quarter-rate v_mad_u64_u32 for a 32-bit multiply-add of an xor)
+				asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(j ^ base0), "s"((uint32_t)(FR_ENT3_F4 * 16)), "v"(ent_lds_v));
+				asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+				             "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\t"
+				             "s_waitcnt lgkmcnt(0)"
+				             : "=&v"(r.a), "=&v"(r.b4), "=&v"(r.q0), "=&v"(r.q1), "=&v"(r.q2) : "v"(addr) : "memory");
 			}
+#ifdef FR_LOOPSTATS
+			dbg_steps++; dbg_cs++;
+#endif
+			const FrWalkGeom g = fr_walk_geom(r, pfx, pfy);
+			const bool kill = fr_walk_update(g, g.ok, T, Cg, Xt, sA, sB, sD);
+#ifdef FR_LOOPSTATS
+			dbg_hits += (g.ok && !kill) ? 1 : 0;
+#endif
+			if (kill) { mask = 0ull; done = true; }
 		}
+#ifdef FR_LOOPSTATS
+		dbg_wsteps += wave_max_i(dbg_cs); dbg_cs = 0;
+#endif
 		FR_V4_STAMP(dbg_tw)
 		// ---- the older half is finished by every lane: its slots are free, the younger half becomes the older one
 		mask >>= 32;

@@ -119,8 +119,8 @@ def test_product_library_is_not_the_experiment_rig(lib):
     names = set()
     for co in codeobj._code_objects(open(so, "rb").read()):
         names |= set(codeobj._functions(co))
-    assert any("k_fisher_tile_v3ILi16ELi4ELb1E" in n for n in names)            # the dominant kernel is there
-    for banned in ("k_fisher_tile_v3w", "k_fisher_tile_v3ILi8ELi8E", "k_fisher_tile_v2ILi25E", "k_pack_staticILi25E", "k_render_forwardILi",
+    assert any("k_fisher_tile_v4" in n for n in names)            # the dominant kernel is there
+    for banned in ("k_fisher_tile_v3w", "k_fisher_tile_v3ILi8ELi8E", "k_fisher_tile_v3ILi16ELi4ELb1E", "k_fisher_tile_v2ILi25E", "k_pack_staticILi25E", "k_render_forwardILi",
                    "k_backward_lin_tileILb0E", "k_backward_lin_walkILb1E", "k_preprocess_viewsILi4E", "k_preprocess_viewsILin4E",
                    "k_preprocess_viewsILi11E"):
         assert not any(banned in n for n in names), banned

@@ -42,7 +42,7 @@ def test_two_rank_bench_equals_one_rank(gpu, tmp_path):
     for j, scaling in ((weak, "weak"), (strong, "strong")):
         assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["config"]["views_total"] == 16 and j["config"]["views_per_gpu"] == 8
         assert j["metric"] == one["metric"] == "candidate-views/sec" and j["value"] > 0 and j["cpu_baseline"] is None
-        assert j["roofline"]["kernel"] == "k_fisher_tile_v3" and j["roofline"]["kernel_ms"] > 0
+        assert j["roofline"]["kernel"] == "k_fisher_tile_v4" and j["roofline"]["kernel_ms"] > 0
     assert one["n_gpus"] == 1 and one["build"]["build_id"].startswith("FRSRC:")
 
 

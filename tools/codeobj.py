@@ -77,5 +77,5 @@ if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = sys.argv[1:]
     so = args.pop(0) if args and args[0].endswith(".so") else os.path.join(root, "fisher-nerf-customized_amd", "fisher_rast", "libfisher_rast.so")
-    for k in (args or ["k_fisher_tile_v3I", "k_preprocess_views", "k_sort_tiles"]):
+    for k in (args or ["k_fisher_tile_v4", "k_preprocess_views", "k_sort_tiles"]):
         print(k, kernel_code_id(so, k))

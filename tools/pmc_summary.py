@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fold the rocprofv3 --pmc passes of tools/pmc_collect.sh (one counter_collection.csv per counter group, merged back under
-gpurun_out/pmc_<tag>_<i>/) into profiles/pmc_k_fisher_tile_v3.json and copy the per-group folds to profiles/<tag>_pmc_<i>.txt.
+gpurun_out/pmc_<tag>_<i>/) into profiles/pmc_k_fisher_tile_v4.json and copy the per-group folds to profiles/<tag>_pmc_<i>.txt.
 The record is stamped with `kernel_code_id`: the sha256 of the profiled kernel's gfx950 machine code, read out of the library the
 counters were taken on (tools/codeobj.py); bench.py recomputes it from the library it has loaded and ignores a record whose id
 differs.  Nothing here is edited by hand.  With view groups a step launches the kernel several times: the counters are summed
@@ -15,13 +15,13 @@ from fisher_rast import _lib   # noqa: E402
 import codeobj                 # noqa: E402
 
 tag = sys.argv[1]
-KERNEL = "k_fisher_tile_v3"
+KERNEL = "k_fisher_tile_v4"
 acc = collections.defaultdict(list)
 files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*", "*counter_collection.csv")))
 assert files, "no counter_collection.csv under gpurun_out/pmc_%s_*" % tag
 for f in files:
     for r in csv.DictReader(open(f)):
-        if (KERNEL + "<") in r["Kernel_Name"]:          # (not k_fisher_tile_v3h, the out_H kernel of the target's H_train)
+        if (KERNEL + "(") in r["Kernel_Name"] or r["Kernel_Name"].strip() == KERNEL:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 # the last 3 steps are the steady-state scorer launches of tools/pmc_target.py; a step = `disp` dispatches of the kernel (view groups)
 # (the target runs the scorer 4 times: one sizing run + 3 launches)
@@ -30,7 +30,7 @@ m = {k: sum(v[-3 * disp:]) / 3.0 for k, v in acc.items()}
 out = {"kernel": KERNEL, "gaussians": 500000, "views": 64, "size": 256, "columns": 4, "round": tag,
        "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip(),
        "source_hash": _lib.source_hash(), "dispatches_per_step": disp,
-       "kernel_code_id": codeobj.kernel_code_id(_lib.SO_PATH, "k_fisher_tile_v3I"),
+       "kernel_code_id": codeobj.kernel_code_id(_lib.SO_PATH, "k_fisher_tile_v4"),
        "command": "rocprofv3 --pmc <group> -d gpurun_out/pmc_<tag>_<i> -o pmc --output-format csv -- python3 tools/pmc_target.py 4   "
                   "(tools/pmc_collect.sh: one pass per counter group, no trace options beside --pmc)"}
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
@@ -48,7 +48,7 @@ if len(sys.argv) > 3:
     out["walk_iterations_per_step"] = int(float(sys.argv[3]))
     out["loop_stats_note"] = ("(pixel, splat) pairs that pass every test of forward.cu:338-363 and wave-level walk iterations of one "
                               "64-view step, counted by a -DFR_LOOPSTATS build (tools/loopstats.py, FR_DEBUG_MODE 5 and 4)")
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v3.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_k_fisher_tile_v4.json"), "w"), indent=1)
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_*.txt"))):
     shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
 print(json.dumps(out, indent=1))
