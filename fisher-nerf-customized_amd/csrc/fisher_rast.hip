@@ -130,6 +130,7 @@ struct FrParams {
 	int VC;                      // views per preprocess workgroup
 	uint32_t tile_cap;           // 0: tile segments packed by the scan; > 0: every (view, tile) owns keys[(v T + t) tile_cap ...), filled by
 	                             // the projection kernel itself (k_preprocess_views_c<.., true>): no scan dependency, no scatter kernel
+	const uint32_t* order;       // [P] or null (fr_fisher_cfg.order): position -> the caller's Gaussian index; records modes of the multi-view front end only
 	int legacy_sort;             // FR_DEBUG_MODE=6: the LDS-resident sort network of round 1 (A/B runs)
 	int prefiltered;             // GaussianRasterizationSettings.prefiltered (single-view API): a near-plane-culled point raises status[3]
 	int ablate;                  // -DFR_ABLATE builds only (tools/fe_ablate.py): FR_DEBUG_MODE 30..34 drop parts of the direct key scatter
@@ -619,7 +620,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_scatter_keys(FrParams p)
 // (defined with the scorer kernels below) one scorer record per visible (view, Gaussian)
 struct FrRecordArgs {
 	const float* H_inv; long long hinv_stride; const float* packed; float4* recq;
-	const float* cov_trace;      // [P] or null: trace of cov3D (k_pack_static), for the early frustum test
+	const float4* mt;            // [P] {mean xyz, trace of cov3D} in processing order (k_pack_static): what phase A of the front end reads
+	const float4* grp;           // [ceil(P / 256)][2] {lo xyz, largest trace} {hi xyz, 0}: bounds of every 256 consecutive Gaussians, or null
+	int early;                   // 1: the early frustum test (and the group test) may be used -- cov3D is the one k_pack_static built
 	// compact records (multi-view front end in a records mode), or null: one 96-byte record {recA, recB, recQ[4]} per SLOT,
 	// slot = projection workgroup * (256 G) + rank of the Gaussian among the workgroup's visible ones of that view -- monotone in
 	// the Gaussian index, so keys that carry the slot sort exactly like keys that carry the index, and a workgroup's records of a
@@ -702,9 +705,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views(FrParams p, FrR
 			//   |J|_F^2 = (fx^2 (1 + jx^2) + fy^2 (1 + jy^2)) / z^2,  jx = min(|x / z|, 1.3 tan_fovx) (the clamp of forward.cu:80-84),
 			// times |W|_2^2 of the view matrix's 3 x 3, and lambda_max(cov3D) <= trace(cov3D) (k_pack_static), so a centre further than
 			// that bound (+ 2 % and 2 px for rounding) outside the tile grid cannot touch it.  NaNs keep the pair.
-			const bool early = RC != 0 && ra.cov_trace != nullptr;
+			const bool early = RC != 0 && ra.early != 0 && ra.mt != nullptr;
 			float tr = 0.f;
-			if (early && live) tr = ra.cov_trace[i];
+			if (early && live) tr = ra.mt[i].w;
 			const float lx = 1.3f * p.tanfovx, ly = 1.3f * p.tanfovy;
 			// |W|_2^2 <= |W|_1 |W|_inf for the 3 x 3 of the view matrix (1 for the identity the scorer's camera has)
 			float wn;
@@ -958,6 +961,74 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 	// bench workload: a full batch and a nearly empty one, had every round been flushed by itself); what is left over after a round
 	// (< 256) moves to the front of the list, the last round flushes.  A pending entry = index inside the workgroup's share | view << 16.
 	const int iw = blockIdx.x * p.G * FR_THREADS;       // the workgroup's first Gaussian
+	const bool early = ra.early != 0;
+	const float lx = 1.3f * p.tanfovx, ly = 1.3f * p.tanfovy;
+	float wn;                                           // |W|_2^2 <= |W|_1 |W|_inf for the 3 x 3 of the view matrix (1 for the identity the scorer's camera has)
+	{
+		const float c0 = fabsf(vm[0]) + fabsf(vm[1]) + fabsf(vm[2]), c1 = fabsf(vm[4]) + fabsf(vm[5]) + fabsf(vm[6]), c2 = fabsf(vm[8]) + fabsf(vm[9]) + fabsf(vm[10]);
+		const float r0 = fabsf(vm[0]) + fabsf(vm[4]) + fabsf(vm[8]), r1 = fabsf(vm[1]) + fabsf(vm[5]) + fabsf(vm[9]), r2 = fabsf(vm[2]) + fabsf(vm[6]) + fabsf(vm[10]);
+		wn = fmaxf(c0, fmaxf(c1, c2)) * fmaxf(r0, fmaxf(r1, r2));
+	}
+	const float fx2 = 1.02f * wn * p.focal_x * p.focal_x, fy2 = 1.02f * wn * p.focal_y * p.focal_y;
+	const float xmax = (float)(p.gx * FR_BLOCK_X + FR_BLOCK_X), ymax = (float)(p.gy * FR_BLOCK_Y + FR_BLOCK_Y);
+	// ---- group test: bit (g nv + vv) of `skipm` = no Gaussian of the workgroup's g-th round of 256 can survive phase A in view vv.
+	// With the Gaussians laid out along a Z-curve (fr_fisher_cfg.order) the 256 of a round are neighbours in space: two thirds of the
+	// (round, view) pairs of the benchmark hold no survivor at all.  The round's bounds (k_pack_static: box of the means, largest
+	// trace) give a sphere (c, R) in world space, hence in the view's camera frame (w2c is rigid).  A Gaussian survives only in front
+	// of the near plane with its centre's pixel within rb of the tile grid, rb = 3 sqrt(kc tr / z^2 + 0.7) + 2 <= a / z + c0 with
+	// a = 3 sqrt(kc_max tr_max), c0 = 3 sqrt(0.7) + 2 (sqrt(u + v) <= sqrt(u) + sqrt(v)).  Where the clip-space w IS the view depth z
+	// (every pinhole projection: row 3 of proj = row 2 of view), `px + rb < 0` for z > 0 follows from the LINEAR inequality
+	// W hx + (W - 1 + 2 c0) z + 2 a < 0 in the camera-frame point, so the whole sphere is out when it holds at the centre with |A| R to
+	// spare; likewise for the other three sides, and for z + R <= 0.001.  Slack: c0 = 6 instead of 4.51, 1 % on a and R.
+	unsigned long long skipm = 0ull;
+	if (early && ra.grp != nullptr && p.G * nv <= 64)
+	{
+		const float wrow = fabsf(pm[3] - vm[2]) + fabsf(pm[7] - vm[6]) + fabsf(pm[11] - vm[10]) + fabsf(pm[15] - vm[14]);
+		const float wmag = fabsf(vm[2]) + fabsf(vm[6]) + fabsf(vm[10]) + fabsf(vm[14]);
+		const bool pinhole = wrow <= 1e-6f * wmag;                     // clip w == view z
+		bool skip = false;
+		const int g = lane / nv, vv = lane - g * nv;
+		const int blk = blockIdx.x * p.G + g;
+		if (pinhole && g < p.G && blk * FR_THREADS < p.P)
+		{
+#pragma clang fp contract(fast)
+			const float4 b0 = ra.grp[2 * (size_t)blk], b1 = ra.grp[2 * (size_t)blk + 1];
+			const fr_f3 cw = { 0.5f * (b0.x + b1.x), 0.5f * (b0.y + b1.y), 0.5f * (b0.z + b1.z) };
+			const float ex = b1.x - cw.x, ey = b1.y - cw.y, ez = b1.z - cw.z;
+			float R = 1.01f * __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) + 1e-6f;
+			const fr_f3 c = has_w2c ? fr_world_to_cam(cw, s_wm + 12 * vv) : cw;
+			if (has_w2c)
+			{
+				// the sphere's radius in the camera frame: times |M|_2 <= sqrt(|M^T M|_inf) of the pose's 3 x 3 (1 for a rigid pose)
+				const float* m = s_wm + 12 * vv;
+				const float g00 = m[0] * m[0] + m[4] * m[4] + m[8] * m[8], g11 = m[1] * m[1] + m[5] * m[5] + m[9] * m[9], g22 = m[2] * m[2] + m[6] * m[6] + m[10] * m[10];
+				const float g01 = fabsf(m[0] * m[1] + m[4] * m[5] + m[8] * m[9]), g02 = fabsf(m[0] * m[2] + m[4] * m[6] + m[8] * m[10]), g12 = fabsf(m[1] * m[2] + m[5] * m[6] + m[9] * m[10]);
+				R *= __builtin_amdgcn_sqrtf(fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22))) * 1.00001f;
+			}
+			const float kcm = fx2 * (1.0f + lx * lx) + fy2 * (1.0f + ly * ly);
+			const float a2 = 2.0f * 1.01f * 3.0f * __builtin_amdgcn_sqrtf(kcm * b0.w);
+			const float c0 = 6.0f;
+			const float Wf = (float)p.W, Hf = (float)p.H;
+			// z and the four sides as linear forms A . c + B of the camera-frame point (view-space z = vm row 2)
+			const float zc = vm[2] * c.x + vm[6] * c.y + vm[10] * c.z + vm[14];
+			const float zn = __builtin_amdgcn_sqrtf(vm[2] * vm[2] + vm[6] * vm[6] + vm[10] * vm[10]);
+			auto side = [&](float sx, float sy, float sz, float sw, float kz, float add) -> bool {
+				// L(q) = s . q + sw + kz z(q) + add ;  returns L(c) + |grad L| R < 0  (the whole sphere on the negative side)
+				const float Ax = sx + kz * vm[2], Ay = sy + kz * vm[6], Az = sz + kz * vm[10];
+				const float Lc = Ax * c.x + Ay * c.y + Az * c.z + (sw + kz * vm[14]) + add;
+				return Lc + __builtin_amdgcn_sqrtf(Ax * Ax + Ay * Ay + Az * Az) * R < 0.f;
+			};
+			// px + rb < 0            <=  W hx + (W - 1 + 2 c0) z + 2 a < 0
+			// px - rb > xmax         <= -W hx - (W - 1 - 2 xmax - 2 c0) z + 2 a < 0
+			const bool left = side(Wf * pm[0], Wf * pm[4], Wf * pm[8], Wf * pm[12], Wf - 1.0f + 2.0f * c0, a2);
+			const bool right = side(-Wf * pm[0], -Wf * pm[4], -Wf * pm[8], -Wf * pm[12], -(Wf - 1.0f - 2.0f * xmax - 2.0f * c0), a2);
+			const bool top = side(Hf * pm[1], Hf * pm[5], Hf * pm[9], Hf * pm[13], Hf - 1.0f + 2.0f * c0, a2);
+			const bool bottom = side(-Hf * pm[1], -Hf * pm[5], -Hf * pm[9], -Hf * pm[13], -(Hf - 1.0f - 2.0f * ymax - 2.0f * c0), a2);
+			const bool behind = zc + zn * R <= 0.001f;
+			skip = left || right || top || bottom || behind;            // (a NaN bound compares false everywhere: the round is kept)
+		}
+		skipm = __builtin_amdgcn_ballot_w64(skip);
+	}
 	uint32_t pend = 0;                                  // survivors waiting, uniform
 	for (int g = 0; g < p.G; g++)
 	{
@@ -965,24 +1036,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 		if (i0 >= p.P) break;
 		const bool last_round = g == p.G - 1 || i0 + FR_THREADS >= p.P;
 		uint32_t np = 0;
+		const uint32_t skipv = (uint32_t)(skipm >> (g * nv)) & ((1u << nv) - 1u);         // views that cannot see this round
 		// ---- phase A (the tests of k_preprocess_views): near-plane + early frustum test, survivors appended to `pairs`
+		if (skipv != (1u << nv) - 1u)
 		{
 			const int i = i0 + tid;
 			const bool live = i < p.P;
 			fr_f3 pw = { 0.f, 0.f, 0.f };
-			if (live) pw = fr_f3{ p.means3D[3 * (size_t)i], p.means3D[3 * (size_t)i + 1], p.means3D[3 * (size_t)i + 2] };
-			const bool early = ra.cov_trace != nullptr;
 			float tr = 0.f;
-			if (early && live) tr = ra.cov_trace[i];
-			const float lx = 1.3f * p.tanfovx, ly = 1.3f * p.tanfovy;
-			float wn;
-			{
-				const float c0 = fabsf(vm[0]) + fabsf(vm[1]) + fabsf(vm[2]), c1 = fabsf(vm[4]) + fabsf(vm[5]) + fabsf(vm[6]), c2 = fabsf(vm[8]) + fabsf(vm[9]) + fabsf(vm[10]);
-				const float r0 = fabsf(vm[0]) + fabsf(vm[4]) + fabsf(vm[8]), r1 = fabsf(vm[1]) + fabsf(vm[5]) + fabsf(vm[9]), r2 = fabsf(vm[2]) + fabsf(vm[6]) + fabsf(vm[10]);
-				wn = fmaxf(c0, fmaxf(c1, c2)) * fmaxf(r0, fmaxf(r1, r2));
-			}
-			const float fx2 = 1.02f * wn * p.focal_x * p.focal_x, fy2 = 1.02f * wn * p.focal_y * p.focal_y;
-			const float xmax = (float)(p.gx * FR_BLOCK_X + FR_BLOCK_X), ymax = (float)(p.gy * FR_BLOCK_Y + FR_BLOCK_Y);
+			if (live) { const float4 m4 = ra.mt[i]; pw = fr_f3{ m4.x, m4.y, m4.z }; tr = m4.w; }
 			// The survivor list has to come out in (view, Gaussian index) order: a visible pair's slot is its rank among the
 			// visible pairs of its view, and the keys rely on that rank being monotone in the index (ties of equal depth).  So the
 			// waves do not append with an atomic cursor: every wave counts its survivors per view, the counts are scanned in
@@ -990,6 +1052,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			uint32_t keepbits = 0;
 			for (int vv = 0; vv < nv; vv++)
 			{
+				if ((skipv >> vv) & 1u) { if (lane == 0) s_ca[vv * 4 + wave] = 0u; continue; }       // (uniform: the whole round is out of this view)
 				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, s_wm + 12 * vv) : pw;
 				const fr_f3 p_view = fr_xform4x3(po, vm);        // (the near-plane decision: the reference's arithmetic, unfused)
 				bool keep = live && !(p_view.z <= 0.001f);
@@ -1068,7 +1131,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				}
 				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
 				sp = fr_preprocess_one(po, c3, vm, pm, p.W, p.H, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.gx, p.gy);
-				if (sp.radius > 0) { o = p.opac[i]; ext = fr_alpha_extent(sp.conx, sp.cony, sp.conz, o); }
+				if (sp.radius > 0) { o = p.opac[p.order ? p.order[i] : (uint32_t)i]; ext = fr_alpha_extent(sp.conx, sp.cony, sp.conz, o); }
 			}
 			const bool vis = sp.radius > 0;
 			// ---- ordered ranks.  The pending list is a sequence of rounds, each sorted by (view, index), so the pairs of one view stand
@@ -1194,7 +1257,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 					en.xy0 = park[10 * FR_THREADS + r]; en.xy1 = park[11 * FR_THREADS + r];
 					*(uint4*)(p.vis_list + ((size_t)v * nblk + blockIdx.x) * cap + (rk & 0xffffu)) = *(const uint4*)&en;
 				}
-				if constexpr (AF != 0) ra.slot_idx[(size_t)v * PV + slot] = idx;    // (the out_H kernels go back to the index)
+				if constexpr (AF != 0) ra.slot_idx[(size_t)v * PV + slot] = p.order ? p.order[idx] : idx;    // (the out_H kernels go back to the caller's index)
 			}
 			__syncthreads();                                        // park[], s_wtot and s_wk are reused by the next batch
 		}
@@ -2300,55 +2363,99 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile(FrParams p, FrFisher
 
 template <int C>
 __global__ __launch_bounds__(FR_THREADS) void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed,
-                                                            float* __restrict__ cov_trace)
+                                                            float4* __restrict__ mt, float4* __restrict__ grp)
 {
 	constexpr int PS = FrPackSize<C>::value;
 	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
-	if (i >= p.P) return;
+	const bool live = i < p.P;
+	// position i of the processing order holds the caller's Gaussian `src` (fr_fisher_cfg.order; the identity without it)
+	const size_t src = live ? (p.order ? (size_t)p.order[i] : (size_t)i) : 0;
 	float b[PS];
 #pragma unroll
 	for (int k = 0; k < PS; k++) b[k] = 0.f;
-#pragma unroll
-	for (int k = 0; k < 3; k++) b[k] = p.means3D[3 * (size_t)i + k];
-#pragma unroll
-	for (int k = 0; k < 6; k++) b[3 + k] = 0.f;
-	if (p.cov3D)
+	if (live)
 	{
 #pragma unroll
-		for (int k = 0; k < 6; k++) b[3 + k] = p.cov3D[6 * (size_t)i + k];
-	}
-	else
-	{
-		// (fr_bin_pipeline leaves cov3D null when this kernel is its only reader: k_cov3d's arithmetic, forward.cu:118-152)
-		const fr_f3 sc = { p.scales[3 * (size_t)i], p.scales[3 * (size_t)i + 1], p.scales[3 * (size_t)i + 2] };
-		const fr_f4 q = { p.rots[4 * (size_t)i], p.rots[4 * (size_t)i + 1], p.rots[4 * (size_t)i + 2], p.rots[4 * (size_t)i + 3] };
-		fr_cov3d(sc, p.mod, q, &b[3]);
+		for (int k = 0; k < 3; k++) b[k] = p.means3D[3 * src + k];
+		if (p.cov3D)
+		{
+#pragma unroll
+			for (int k = 0; k < 6; k++) b[3 + k] = p.cov3D[6 * src + k];
+		}
+		else
+		{
+			// (fr_bin_pipeline leaves cov3D null when this kernel is its only reader: k_cov3d's arithmetic, forward.cu:118-152)
+			const fr_f3 sc = { p.scales[3 * src], p.scales[3 * src + 1], p.scales[3 * src + 2] };
+			const fr_f4 q = { p.rots[4 * src], p.rots[4 * src + 1], p.rots[4 * src + 2], p.rots[4 * src + 3] };
+			fr_cov3d(sc, p.mod, q, &b[3]);
+		}
+#pragma unroll
+		for (int k = 0; k < 3; k++) b[9 + k] = p.colors[3 * src + k];
+		int o = 12;
+		if constexpr (C >= 11)
+		{
+#pragma unroll
+			for (int k = 0; k < 3; k++) b[12 + k] = p.scales[3 * src + k];
+#pragma unroll
+			for (int k = 0; k < 4; k++) b[15 + k] = p.rots[4 * src + k];
+			o = 19;
+		}
+		if constexpr (C <= 11)
+		{
+			if (H_inv)
+			{
+#pragma unroll
+				for (int c = 0; c < C; c++) b[o + c] = H_inv[src * C + c];
+			}
+		}
+		float4* dst = (float4*)(packed + (size_t)i * PS);
+#pragma unroll
+		for (int k = 0; k < PS / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
 	}
 	// xx + yy + zz of the symmetric 3 x 3: an upper bound of its largest eigenvalue (the tighter (mod * largest scale)^2 only
 	// holds for unit quaternions, which forward.cu:120-151 does not require)
-	if (cov_trace) cov_trace[i] = b[3] + b[6] + b[8];
-#pragma unroll
-	for (int k = 0; k < 3; k++) b[9 + k] = p.colors[3 * (size_t)i + k];
-	int o = 12;
-	if constexpr (C >= 11)
+	const float tr = b[3] + b[6] + b[8];
+	if (mt && live) mt[i] = make_float4(b[0], b[1], b[2], tr);
+	if (grp)
 	{
+		// bounds of this workgroup's 256 Gaussians = one 256-Gaussian round of the projection kernel: the box of the means and the largest
+		// trace (a NaN anywhere makes the box NaN, which no test of the projection kernel rejects)
+		__shared__ float s_b[4][7];
+		float lo[3], hi[3], tm = live ? tr : 0.f;
 #pragma unroll
-		for (int k = 0; k < 3; k++) b[12 + k] = p.scales[3 * (size_t)i + k];
+		for (int k = 0; k < 3; k++) { lo[k] = live ? b[k] : 3.0e38f; hi[k] = live ? b[k] : -3.0e38f; }
+		const bool bad = live && !(b[0] == b[0] && b[1] == b[1] && b[2] == b[2] && tr == tr);
 #pragma unroll
-		for (int k = 0; k < 4; k++) b[15 + k] = p.rots[4 * (size_t)i + k];
-		o = 19;
-	}
-	if constexpr (C <= 11)
-	{
-		if (H_inv)
+		for (int d = 32; d >= 1; d >>= 1)
 		{
 #pragma unroll
-			for (int c = 0; c < C; c++) b[o + c] = H_inv[(size_t)i * C + c];
+			for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], d, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d, 64)); }
+			tm = fmaxf(tm, __shfl_xor(tm, d, 64));
+		}
+		const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+		const int w = threadIdx.x >> 6;
+		if ((threadIdx.x & 63) == 0)
+		{
+			const float nan = __uint_as_float(0x7fc00000u);
+			for (int k = 0; k < 3; k++) { s_b[w][k] = any_bad ? nan : lo[k]; s_b[w][3 + k] = hi[k]; }
+			s_b[w][6] = tm;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			float L[3], Hh[3], t = s_b[0][6];
+			bool nn = false;
+			for (int k = 0; k < 3; k++) { L[k] = s_b[0][k]; Hh[k] = s_b[0][3 + k]; }
+			for (int ww = 0; ww < 4; ww++)
+			{
+				for (int k = 0; k < 3; k++) { nn = nn || !(s_b[ww][k] == s_b[ww][k]); L[k] = fminf(L[k], s_b[ww][k]); Hh[k] = fmaxf(Hh[k], s_b[ww][3 + k]); }
+				t = fmaxf(t, s_b[ww][6]);
+			}
+			const float nan = __uint_as_float(0x7fc00000u);
+			grp[2 * (size_t)blockIdx.x] = make_float4(nn ? nan : L[0], L[1], L[2], t);
+			grp[2 * (size_t)blockIdx.x + 1] = make_float4(Hh[0], Hh[1], Hh[2], 0.f);
 		}
 	}
-	float4* dst = (float4*)(packed + (size_t)i * PS);
-#pragma unroll
-	for (int k = 0; k < PS / 4; k++) dst[k] = make_float4(b[4 * k], b[4 * k + 1], b[4 * k + 2], b[4 * k + 3]);
 }
 
 #define FR_E255 (-7.994353436858858f)     // log2(1/255)
@@ -2905,8 +3012,10 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	float4* sp = (float4*)(p.splat + (size_t)v * p.P + id);
 	float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;          // {x, y, cx, cy} {cz, o, depth, ext}
 	float opacity;
+	// (p.order: `id` is a position of the processing order; opacity and per-view weights are read at the caller's index)
+	const uint32_t oid = p.order ? p.order[id] : id;
 	if constexpr (REWRITE) { a0 = sp[0]; a1 = sp[1]; opacity = a1.y; }
-	else opacity = p.opac[id];
+	else opacity = p.opac[oid];
 	float gsv[PS];
 	const float4* pk = (const float4*)(packed + (size_t)id * PS);
 #pragma unroll
@@ -2949,7 +3058,7 @@ __device__ __forceinline__ void fr_fisher_record_one(const FrParams& p, const fl
 	float hv[C];
 	if (hinv_stride != 0)
 	{
-		const float* hp = H_inv + (size_t)v * hinv_stride + (size_t)id * C;
+		const float* hp = H_inv + (size_t)v * hinv_stride + (size_t)oid * C;
 #pragma unroll
 		for (int c = 0; c < C; c++) hv[c] = hp[c];
 	}
@@ -3009,7 +3118,7 @@ __device__ __forceinline__ void fr_fisher_record_general(const FrParams& p, cons
 	float Bg[6][3];
 	// IEEE division (not v_rcp_f32): these records feed per-ENTRY outputs (1e-4 per element, near-plane splats included)
 	fr_mean_rows_g<false>(po, &gsv[3], vm, pm, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, p.W, p.H, Rg, SR ? Bg : nullptr, nullptr, nullptr);
-	const float opacity = p.opac[id];
+	const float opacity = p.opac[p.order ? p.order[id] : id];
 	const float inv_o = 1.0f / opacity;
 	out[2] = make_float4(Rg[0][0], Rg[0][1], Rg[0][2], Rg[0][3]);
 	out[3] = make_float4(Rg[0][4], Rg[1][0], Rg[1][1], Rg[1][2]);
@@ -5586,6 +5695,7 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 	p.means3D = g->means3D; p.colors = g->colors_precomp; p.shs = g->shs; p.opac = g->opacities;
 	p.scales = g->scales; p.rots = g->rotations;
 	p.VC = 1;
+	p.order = nullptr;
 	p.legacy_sort = fr_debug_mode() == 6;
 	FR_ABL(p.ablate = fr_debug_mode();)
 }
@@ -5673,7 +5783,7 @@ struct FrJoinGuard {
 // Score-only mode: the front end also produces the scorer's per-(view, Gaussian) records (k_pack_static, then phase C of
 // k_preprocess_views; with the single-view front end, k_fisher_records after k_scatter_keys, beside the sorts, on the second side stream).
 struct FrScorerPlan { int columns; bool form_a; FrRecordArgs ra; bool skip_pack = false; bool general = false; };   // general: out_H records of k_fisher_tile_v3g   // skip_pack: a view group after the first (the packed static records are per call)     // form_a: out_H mode, the records carry the mean Jacobian (k_fisher_tile_v3h)
-template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed, float* __restrict__ cov_trace);
+template <int C> __global__ void k_pack_static(FrParams p, const float* __restrict__ H_inv, float* __restrict__ packed, float4* __restrict__ mt, float4* __restrict__ grp);
 template <int C, bool LIST, bool FORM_A> __global__ void k_fisher_records(FrParams p, FrRecordArgs ra);
 
 static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, const FrScorerPlan* plan = nullptr)
@@ -5706,8 +5816,8 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	{
 		const float* shared_hinv = plan->ra.hinv_stride ? nullptr : plan->ra.H_inv;
 		dim3 gp((P + FR_THREADS - 1) / FR_THREADS);
-		if (plan->columns == 4) hipLaunchKernelGGL((k_pack_static<4>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float*)plan->ra.cov_trace);
-		else hipLaunchKernelGGL((k_pack_static<11>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float*)plan->ra.cov_trace);
+		if (plan->columns == 4) hipLaunchKernelGGL((k_pack_static<4>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float4*)plan->ra.mt, (float4*)plan->ra.grp);
+		else hipLaunchKernelGGL((k_pack_static<11>), gp, dim3(FR_THREADS), 0, s, p, shared_hinv, (float*)plan->ra.packed, (float4*)plan->ra.mt, (float4*)plan->ra.grp);
 		if ((rc = fr_check_launch("k_pack_static"))) return rc;
 	}
 	FrJoinGuard joins(s);
@@ -5723,7 +5833,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		auto lds_c_of = [&](int vc) { return fr_lds_views_c(vc, p.T, p.tile_cap != 0); };
 		dim3 gridV(gridP.x, (p.V + p.VC - 1) / p.VC);
 		const size_t lds = ((size_t)p.VC * p.T + (size_t)FR_THREADS * p.VC + 12 * (size_t)p.VC + 2 * (size_t)p.VC * 8 * (size_t)p.G) * 4;
-		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 6 };
+		FrRecordArgs ra = plan ? plan->ra : FrRecordArgs{ nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 6 };
 		// The records are phase C of the projection kernel.  (Measured on MI355X, 500k Gaussians x 64 views: as a kernel of their
 		// own beside scan / scatter / sort -- on a second stream, also at the lowest stream priority -- the step takes 2.62 ms
 		// against 2.53 ms: the records' waves slow the latency-bound scatter and the one-workgroup-per-CU sort tier down.)
@@ -5971,7 +6081,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		uint8_t* fallback = (uint8_t*)p.tile_fill;
 		FrParams pp = p;
 		pp.colors = g->colors_precomp;
-		hipLaunchKernelGGL((k_pack_static<25>), dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, pp, (const float*)nullptr, packed, (float*)nullptr);
+		hipLaunchKernelGGL((k_pack_static<25>), dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, pp, (const float*)nullptr, packed, (float4*)nullptr, (float4*)nullptr);
 		FrFisherArgs f;
 		memset(&f, 0, sizeof(f));
 		f.dL_img = dL_dout_color; f.dL_stride = 0;
@@ -6127,7 +6237,7 @@ static int fr_debug_mode()
 
 #define FR_MAX_GROUPS 4              // view groups of one fr_fisher_views call (fr_pick_groups)
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, recq, slot_idx, packed, cov_trace, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, w2c_inv, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, slot_idx, packed, mt, grp, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, w2c_inv, status, keys, fallback, total;
 	size_t PV;                   // slots per view of the compact records: projection workgroups * 256 G (>= P)
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
@@ -6148,7 +6258,8 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.recq = o; o = fr_align(o + VPV * (columns == 11 ? 208 : 112));     // compact: 96 B (score form, A-form), 112 / 208 B (general out_H form, 4 / 11 columns)
 	L.slot_idx = o; o = fr_align(o + VPV * 4);
 	L.packed = o; o = fr_align(o + (size_t)P * 4 * (size_t)(columns == 11 ? 32 : 16));
-	L.cov_trace = o; o = fr_align(o + (size_t)P * 4);
+	L.mt = o; o = fr_align(o + (size_t)P * 16);
+	L.grp = o; o = fr_align(o + (size_t)((P + FR_THREADS - 1) / FR_THREADS) * 32);
 	L.big_list = o; o = fr_align(o + (size_t)(V * T) * 4 + 64 * FR_MAX_GROUPS);      // one {count, pad[15], list} per view group
 	L.view_work = o; o = fr_align(o + (size_t)V * 4);
 	L.view_perm = o; o = fr_align(o + (size_t)V * 4);
@@ -6260,7 +6371,7 @@ static void fr_launch_fisher(FrParams& p, FrFisherArgs f, float* packed, uint8_t
 	const bool per_view = hi && f.hinv_stride != 0;
 	// wave-private passes over the sorted keys; tiles whose lists do not fit the LDS index are flagged ...
 	f.only_flagged = nullptr;
-	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed, (float*)nullptr);
+	hipLaunchKernelGGL((k_pack_static<C>), dim3((p.P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, (hi && !per_view) ? f.H_inv : nullptr, packed, (float4*)nullptr, (float4*)nullptr);
 	// measurement hook: events around the dominant kernel only, on the stream it runs on
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_prof_on)
@@ -6400,7 +6511,11 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	}
 	// the early frustum test needs a positive semi-definite cov3D: the one k_cov3d builds, not a caller's precomputed one;
 	// FR_DEBUG_MODE=15 switches it off (A/B runs)
-	plan.ra.cov_trace = (g->cov3D_precomp || f.debug_mode == 15) ? nullptr : (const float*)(ws + L.cov_trace);
+	plan.ra.mt = (const float4*)(ws + L.mt);
+	plan.ra.grp = (const float4*)(ws + L.grp);
+	plan.ra.early = (g->cov3D_precomp || f.debug_mode == 15) ? 0 : 1;
+	// the processing order is honoured where the compact-record front end runs (it is a layout hint: the other paths ignore it)
+	p.order = compact ? fc->order : nullptr;
 
 	// ---- view groups (off by default: fr_pick_groups has the measurement).  The front end (projection, records, scan, scatter,
 	// sorts: ~1.1 ms at 500k Gaussians x 64 views) waits on memory for half its wave cycles, the tile kernel (~1.0 ms) is bound by
@@ -6847,19 +6962,9 @@ extern "C" size_t fr_knn_workspace_bytes(int32_t P)
 	return fr_knn_layout(P).total;
 }
 
-extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, fr_stream_t stream)
+// keys[i] = Morton code of point i << 32 | i, sorted ascending (unique keys: the order is that of a stable sort by code)
+static int fr_morton_sort(int P, const float* points, uint64_t* keys, uint32_t* mm, hipStream_t s)
 {
-	if (P < 0) return fr_fail(FR_EINVAL, "fr_knn_dist2: P < 0");
-	if (P == 0) return FR_OK;
-	if (!points || !out || !workspace) return fr_fail(FR_EINVAL, "fr_knn_dist2: null pointer");
-	FrKnnLayout L = fr_knn_layout(P);
-	if (workspace_bytes < L.total) return fr_fail(FR_ENOSPACE, "fr_knn_dist2: workspace smaller than fr_knn_workspace_bytes()");
-	hipStream_t s = (hipStream_t)stream;
-	char* ws = (char*)workspace;
-	uint64_t* keys = (uint64_t*)(ws + L.keys);
-	float* sorted = (float*)(ws + L.sorted);
-	float* boxes = (float*)(ws + L.boxes);
-	uint32_t* mm = (uint32_t*)(ws + L.mm);
 	int rc;
 	(void)hipMemsetAsync(mm, 0xFF, 12, s);
 	(void)hipMemsetAsync(mm + 3, 0x00, 12, s);
@@ -6884,7 +6989,51 @@ extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* wo
 			hipLaunchKernelGGL(k_bitonic_global, dim3(gblk), dim3(FR_THREADS), 0, s, keys, n, half_pairs, k, j);
 		hipLaunchKernelGGL(k_bitonic_chunk_merge, dim3(nchunks), dim3(FR_THREADS), 0, s, keys, n);
 	}
-	if ((rc = fr_check_launch("k_bitonic_global"))) return rc;
+	return fr_check_launch("k_bitonic_global");
+}
+
+// ---- fr_spatial_order: the Gaussians along a Z-curve (fr_fisher_cfg.order) ---------------------------------------------------
+__global__ __launch_bounds__(FR_THREADS) void k_order_from_keys(int P, const uint64_t* __restrict__ keys, uint32_t* __restrict__ order)
+{
+	const int i = blockIdx.x * FR_THREADS + threadIdx.x;
+	if (i < P) order[i] = (uint32_t)keys[i];
+}
+extern "C" size_t fr_spatial_order_workspace_bytes(int32_t P)
+{
+	if (P < 0) return 0;
+	return fr_align((size_t)P * 8) + 256;
+}
+extern "C" int fr_spatial_order(int32_t P, const float* means3D, uint32_t* order_out, void* workspace, size_t workspace_bytes, fr_stream_t stream)
+{
+	if (P < 0) return fr_fail(FR_EINVAL, "fr_spatial_order: P < 0");
+	if (P == 0) return FR_OK;
+	if (!means3D || !order_out || !workspace) return fr_fail(FR_EINVAL, "fr_spatial_order: null pointer");
+	if (workspace_bytes < fr_spatial_order_workspace_bytes(P)) return fr_fail(FR_ENOSPACE, "fr_spatial_order: workspace smaller than fr_spatial_order_workspace_bytes()");
+	hipStream_t s = (hipStream_t)stream;
+	uint64_t* keys = (uint64_t*)workspace;
+	uint32_t* mm = (uint32_t*)((char*)workspace + fr_align((size_t)P * 8));
+	int rc;
+	if ((rc = fr_morton_sort(P, means3D, keys, mm, s))) return rc;
+	hipLaunchKernelGGL(k_order_from_keys, dim3((P + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, s, P, (const uint64_t*)keys, order_out);
+	return fr_check_launch("k_order_from_keys");
+}
+
+extern "C" int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, fr_stream_t stream)
+{
+	if (P < 0) return fr_fail(FR_EINVAL, "fr_knn_dist2: P < 0");
+	if (P == 0) return FR_OK;
+	if (!points || !out || !workspace) return fr_fail(FR_EINVAL, "fr_knn_dist2: null pointer");
+	FrKnnLayout L = fr_knn_layout(P);
+	if (workspace_bytes < L.total) return fr_fail(FR_ENOSPACE, "fr_knn_dist2: workspace smaller than fr_knn_workspace_bytes()");
+	hipStream_t s = (hipStream_t)stream;
+	char* ws = (char*)workspace;
+	uint64_t* keys = (uint64_t*)(ws + L.keys);
+	float* sorted = (float*)(ws + L.sorted);
+	float* boxes = (float*)(ws + L.boxes);
+	uint32_t* mm = (uint32_t*)(ws + L.mm);
+	int rc;
+	const int nblk = (P + FR_THREADS - 1) / FR_THREADS;
+	if ((rc = fr_morton_sort(P, points, keys, mm, s))) return rc;
 	hipLaunchKernelGGL(k_knn_gather, dim3(nblk), dim3(FR_THREADS), 0, s, P, points, keys, sorted);
 	const int nb = (P + FR_KNN_BOX - 1) / FR_KNN_BOX;
 	hipLaunchKernelGGL(k_knn_boxes, dim3(nb), dim3(FR_THREADS), 0, s, P, sorted, boxes);

@@ -62,6 +62,7 @@ class FisherCfg(ctypes.Structure):
         ("dL_image_view_stride", ctypes.c_int64),
         ("tile_capacity", ctypes.c_int32),
         ("poses_are_c2w", ctypes.c_int32),
+        ("order", ctypes.c_void_p),
     ]
 
 
@@ -83,7 +84,7 @@ class OccCfg(ctypes.Structure):
 EXPORTS = (
     "fr_version", "fr_last_error", "fr_build_id", "fr_init", "fr_fisher_workspace_layout", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
     "fr_forward", "fr_backward", "fr_forward_pair", "fr_forward_features", "fr_backward_pair", "fr_fisher_workspace_bytes", "fr_fisher_views",
-    "fr_densify_stats", "fr_densify_masks", "fr_prune_mask", "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_profile_enable", "fr_profile_fetch",
+    "fr_densify_stats", "fr_densify_masks", "fr_prune_mask", "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_spatial_order_workspace_bytes", "fr_spatial_order", "fr_profile_enable", "fr_profile_fetch",
     "fr_occ_workspace_bytes", "fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of",
     "fr_occ_ring_candidates", "fr_occ_free_candidates",
 )
@@ -186,6 +187,10 @@ def load():
     lib.fr_knn_workspace_bytes.argtypes = [ctypes.c_int32]
     lib.fr_knn_dist2.restype = ctypes.c_int
     lib.fr_knn_dist2.argtypes = [ctypes.c_int32, _f32p, _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.fr_spatial_order_workspace_bytes.restype = ctypes.c_size_t
+    lib.fr_spatial_order_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.fr_spatial_order.restype = ctypes.c_int
+    lib.fr_spatial_order.argtypes = [ctypes.c_int32, _f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.fr_profile_enable.restype = ctypes.c_int
     lib.fr_profile_enable.argtypes = [ctypes.c_int]
     lib.fr_profile_fetch.restype = ctypes.c_int

@@ -180,13 +180,33 @@ typedef struct fr_fisher_cfg {
 	                               fills itself -- no scan dependency and no scatter kernel; needs n_views * tiles * tile_capacity
 	                               <= max_rendered (and < 2^32).  A tile with more instances than that: overflow, status[3] = 1. */
 	int32_t poses_are_c2w;      /* 1: `w2c` holds camera-to-world poses; the library inverts them (one small kernel) */
+	const uint32_t* order;      /* device [P] or null: a permutation of 0..P-1 -- the order in which the Gaussians are laid out and
+	                               processed inside the call (fr_spatial_order: Morton order of the means).  Purely a layout
+	                               hint: every input and output keeps the caller's indexing (H_inv rows, out_H rows), the contributor
+	                               sets and their depth order are unchanged.  With a spatially coherent order a projection workgroup's
+	                               256 Gaussians are neighbours in space: whole groups fall outside a view and are skipped by one bounding
+	                               test, a workgroup's keys land in a handful of tiles, a tile's records sit side by side in memory.
+	                               (Splats of EQUAL depth in one tile are ordered by their place in `order`; fr_spatial_order is stable
+	                               -- equal means keep the caller's order -- so duplicated Gaussians composite as in the reference.)
+	                               Ignored by the fall-back kernels (H_inv and out_H in one launch, images beyond 4096 tiles). */
 } fr_fisher_cfg;
+
+/* Morton (Z-curve, 10 bits per axis over the bounding box of the means) order of P points: order_out[k] = index of the k-th point
+ * along the curve; points with equal codes keep their index order (a stable sort).  The reference has no counterpart: it processes
+ * the Gaussians in the order of the parameter tensors (models/SLAM/gaussian.py:1529-1543).  Once per map, not per call. */
+size_t fr_spatial_order_workspace_bytes(int32_t P);
+int fr_spatial_order(int32_t P, const float* means3D, uint32_t* order_out, void* workspace, size_t workspace_bytes, fr_stream_t stream);
 
 size_t fr_fisher_workspace_bytes(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns);
 /* Byte offsets of the named sections inside the scorer's workspace (for tests / debuggers):
  * [0] tile_count u32[V,T], [1] tile_offset u32[V,T], [2] keys u64[R] (sorted per (view, tile) from tile_offset on: (depth_bits << 32) |
  *     record slot with packed lists, (depth_bits << 32) | slot << 4 | strips of the tile reached with fixed segments -- tile_capacity),
- * [3] per-(view, Gaussian) 32-byte records [V,P] (valid where visible), [4] per-(view, Gaussian) 64-byte scorer records [V,P],
+ * [3] dense {recA, recB} records [V,P] x 32 B -- only the single-view front end (images beyond 4096 tiles) fills them; the default
+ *     path leaves this section unused -- [4] the scorer's records: COMPACT [V][PV] records, PV = projection workgroups x their
+ *     Gaussians (>= P), one per visible (view, Gaussian) at slot = workgroup * its Gaussians + rank among the workgroup's visible
+ *     splats of the view: 80 B (score form with fixed key segments: {x, y, k3, log2 o} {-cx/2, -cy, -cz/2, r+g+b} + 12 polynomial
+ *     coefficients), 96 B (score form with packed lists, A-form of the 4-column out_H kernel), 112 / 208 B (general out_H form, 4 / 11
+ *     columns); dense [V,P] x 64 B with the single-view front end,
  * [5] tile_scores f32[V,T], [6] status i32[4], [7] visible-list lengths u32[V, blocks] */
 int fr_fisher_workspace_layout(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t max_rendered, int32_t columns,
                                size_t offsets[8]);
@@ -232,7 +252,7 @@ int fr_knn_dist2(int32_t P, const float* points, float* out, void* workspace, si
 /* ---- measurement hooks (not part of the reference surface) ------------------------------------------ */
 
 /* When enabled, every fr_fisher_views call records a pair of HIP events around its dominant kernel
- * (k_fisher_tile_v3 in the score-only mode, k_fisher_tile_v2 otherwise) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
+ * (k_fisher_tile_v4 / _v3 in the score-only mode, k_fisher_tile_v3h / _v3g / _v2 otherwise) on the stream the kernel is launched on.  Enabling or disabling clears the record. */
 int fr_profile_enable(int on);
 /* Waits for the recorded events and writes up to max_n per-launch durations in milliseconds; returns the count
  * (or -1 on a HIP error).  This is the only entry point that blocks. */
