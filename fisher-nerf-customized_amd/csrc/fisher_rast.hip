@@ -3745,6 +3745,42 @@ void k_fisher_tile_v4(FrParams p, FrFisherArgs f)
 //   flush    per chunk, consecutive lanes on consecutive columns of one Gaussian (global float atomics into out_H).
 // Against k_fisher_tile_v2 this drops the per-chunk Jacobian chains (they are in the records), the contributor lists and
 // the back-to-front order.
+// Neighbouring pixel-lanes walk the same splat in the same step most of the time, and ds_add_f64 serialises lanes that hit one
+// address (8.6 cycles per wave instruction on 64 distinct addresses, 44 with four lanes per address: tools/lds_atomic_rate.hip) --
+// a third of k_fisher_tile_v3h's time (tools/fe_ablate.py --outh).  So before the LDS adds every lane collects, from the other three
+// lanes of its aligned QUAD (four consecutive pixels of a row; quad_perm DPP, no LDS), the values of those that hold the SAME
+// candidate, and only the first lane of such a group issues the adds -- with the group's sum (float adds of at most four terms, then
+// the double accumulator).  key < 0: the lane contributes nothing.  Returns whether this lane issues.
+template <int N>
+__device__ __forceinline__ bool fr_quad_combine(int key, float (&h)[N], int lane)
+{
+	const int q = lane & 3;
+	float add[N];
+#pragma unroll
+	for (int k = 0; k < N; k++) add[k] = 0.f;
+	bool first = key >= 0;
+	// rotation r: lane q reads lane (q + r) & 3 of its quad.  (A source lane that is not executing leaves `old`: key -1, value 0.)
+#define FR_QC_ROUND(CTRL, LOWER)                                                                                                   \
+	{                                                                                                                              \
+		const int ko = __builtin_amdgcn_update_dpp(-1, key, CTRL, 0xf, 0xf, false);                                                \
+		const bool same = ko == key && key >= 0;                                                                                   \
+		const float mk = same ? 1.0f : 0.0f;                                                                                       \
+		_Pragma("unroll") for (int k = 0; k < N; k++)                                                                              \
+		{                                                                                                                          \
+			const float ho = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, h[k]), CTRL, 0xf, 0xf, false)); \
+			add[k] = __builtin_fmaf(mk, ho, add[k]);                                                                               \
+		}                                                                                                                          \
+		first = first && !(same && (LOWER));                                                                                       \
+	}
+	FR_QC_ROUND(0x39, q == 3)          // quad_perm [1,2,3,0]: the source is a lower lane only for q = 3
+	FR_QC_ROUND(0x4E, q >= 2)          // quad_perm [2,3,0,1]
+	FR_QC_ROUND(0x93, q >= 1)          // quad_perm [3,0,1,2]
+#undef FR_QC_ROUND
+#pragma unroll
+	for (int k = 0; k < N; k++) h[k] += add[k];
+	return first;
+}
+
 struct FrPairAlpha { bool ok; float dx, dy, a_un, alpha, om1; };
 __device__ __forceinline__ FrPairAlpha fr_pair_alpha(const fr_v4f& a, const fr_v4f& b4, float pfx, float pfy)
 {
@@ -4322,13 +4358,14 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 			{
 				const int j = __ffsll((long long)mask) - 1;
 				mask &= mask - 1ull;
-				float h0, h1, h2, h3; bool con;
-				const bool kill = pair(ent_lds + (uint32_t)j * (FR_ENT_F4 * 16), h0, h1, h2, h3, con);
+				float h[4]; bool con;
+				const bool kill = pair(ent_lds + (uint32_t)j * (FR_ENT_F4 * 16), h[0], h[1], h[2], h[3], con);
+				const bool issue = fr_quad_combine<4>(con ? j : -1, h, lane);     // same-candidate neighbours of the quad add up first
 				FR_ABL(if (f.debug_mode != 29))                 // 29: ... and without the LDS atomics
-				if (con)
+				if (issue)
 				{
-					atomicAdd(&acc[0][j], (double)h0); atomicAdd(&acc[1][j], (double)h1);
-					atomicAdd(&acc[2][j], (double)h2); atomicAdd(&acc[3][j], (double)h3);
+					atomicAdd(&acc[0][j], (double)h[0]); atomicAdd(&acc[1][j], (double)h[1]);
+					atomicAdd(&acc[2][j], (double)h[2]); atomicAdd(&acc[3][j], (double)h[3]);
 				}
 				if (kill) { mask = 0ull; done = true; }
 			}
@@ -4456,18 +4493,23 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFi
 				const float l0 = q0.x * u0 + q0.y * u1 + q0.z * u2 + q0.w * u3 + q1.x * u4;
 				const float l1 = q1.y * u0 + q1.z * u1 + q1.w * u2 + q2.x * u3 + q2.y * u4;
 				const float l2 = q2.z * u0 + q2.w * u1 + q3.x * u2 + q3.y * u3 + q3.z * u4;
-				atomicAdd(&acc[0][j], (double)(w2 * (l0 * l0))); atomicAdd(&acc[1][j], (double)(w2 * (l1 * l1)));
-				atomicAdd(&acc[2][j], (double)(w2 * (l2 * l2))); atomicAdd(&acc[3][j], (double)(w2 * q3.w));
+				float h[NC];
+				h[0] = w2 * (l0 * l0); h[1] = w2 * (l1 * l1); h[2] = w2 * (l2 * l2); h[3] = w2 * q3.w;
 				if constexpr (NC >= 11)
 				{
-					__builtin_amdgcn_sched_barrier(0);
 					const float* cf = (const float*)&ent[j][2 + 5];              // seven rows x 3 over (ux^2, ux uy, uy^2)
 #pragma unroll
 					for (int r = 0; r < 7; r++)
 					{
 						const float l = cf[3 * r] * u2 + cf[3 * r + 1] * u3 + cf[3 * r + 2] * u4;
-						atomicAdd(&acc[4 + r][j], (double)(w2 * (l * l)));
+						h[4 + r] = w2 * (l * l);
 					}
+				}
+				// (only contributing lanes are here: the others neither offer a value nor take one -- fr_quad_combine)
+				if (fr_quad_combine<NC>(j, h, lane))
+				{
+#pragma unroll
+					for (int c = 0; c < NC; c++) atomicAdd(&acc[c][j], (double)h[c]);
 				}
 			}
 			if (kill) { mask = 0ull; done = true; }
