@@ -4256,9 +4256,32 @@ __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, u
 	}
 }
 
-template <int BW, int BH>
+// MODE 0: one workgroup per (tile, view) walks the whole list twice (many views: the grid fills the chip).
+// MODE 1 / 2 -- FEW views (compute_Hessian of one pose, the tester's per-path-step call: 256 tiles on 256 CUs, the time set by the
+// longest list): the lists are cut into segments of L keys, L = the launch's mean list length (status[0] / tiles, at least 256), so
+// that there are at most 2 x tiles segments in all.  MODE 1 is pass 1 alone, segment after segment; it enters the tile's segments in
+// a work list and leaves every pixel's state {T, colour prefix, finished} at each segment's start, plus the pixel's X.  MODE 2 is
+// pass 2 of ONE segment per workgroup (grid = 2 x tiles; a workgroup beyond the list leaves -- an empty workgroup still costs its
+// dispatch, ~50 ns, which is why the grid is not tiles x the longest list's segments), started from the saved state.  Pass 1 stays sequential per tile: the transmittance chain T <- T (1 - alpha) is rounded
+// at every step and its 1e-4 cut decides who contributes, so no segment can know its start state before its predecessors have run --
+// but pass 1 is the light pass (two ds_read_b128 and ~30 instructions per pair, no accumulators), pass 2 the heavy one.  A pixel's
+// pairs go through exactly the arithmetic of MODE 0, in the same order.
+#define FR_SEG_TILES 1024             // (view, tile) pairs up to which an out_H launch cuts its lists into segments (4 views at 256 x 256)
+struct FrSegArgs {
+	float* snapT;                // [2 V T][256]: T at the start of work-list entry e (negative: the pixel is finished)
+	double* snapC;               // [2 V T][256]: colour prefix there
+	double* X;                   // [V T][256]
+	uint32_t* list;              // [0] = entries (zeroed by the launcher), [1 + e] = (view * T + tile) << 12 | segment of the tile
+};
+__device__ __forceinline__ uint32_t fr_seg_length(const FrParams& p)
+{
+	const uint32_t tiles = (uint32_t)(p.V * p.T);
+	const uint32_t L = (((uint32_t)p.status[0] + tiles - 1u) / tiles + 63u) & ~63u;     // sum over tiles of ceil(n / L) <= 2 tiles
+	return L < 256u ? 256u : L;
+}
+template <int BW, int BH, int MODE = 0>
 __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ recq)
+void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ recq, FrSegArgs sg)
 {
 	static_assert(BW * BH == 64 && 16 % BW == 0, "a wave owns 64 pixels of the tile");
 	__shared__ uint32_t s_q[4][FR_QCAP];
@@ -4270,7 +4293,17 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	uint32_t tile; int v;
-	fr_tile_of_block(p, tile, v);
+	uint32_t seg = 0;                              // MODE 2: this workgroup's segment
+	if constexpr (MODE == 2)
+	{
+		if (blockIdx.x >= sg.list[0]) return;      // (uniform) beyond the work list
+		const uint32_t en = sg.list[1 + blockIdx.x];
+		const uint32_t vtb = en >> 12;
+		seg = en & 4095u;
+		v = (int)(vtb / (uint32_t)p.T); tile = vtb % (uint32_t)p.T;
+	}
+	else if constexpr (MODE == 1) { v = (int)(blockIdx.x / (uint32_t)p.T); tile = blockIdx.x % (uint32_t)p.T; }
+	else fr_tile_of_block(p, tile, v);
 	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
 	constexpr int WPR = 16 / BW;
 	const uint32_t bx0 = tx * FR_BLOCK_X + (uint32_t)(wave % WPR) * BW, by0 = ty * FR_BLOCK_Y + (uint32_t)(wave / WPR) * BH;
@@ -4279,8 +4312,11 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	const float pfx = (float)pxx, pfy = (float)pxy;
 	const size_t vt = (size_t)v * p.T + tile;
 	const size_t vP = (size_t)v * p.P;
-	const uint32_t n = p.tile_cnt[vt];
-	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const uint32_t n_all = p.tile_cnt[vt];
+	const uint32_t segL = MODE == 0 ? 0u : fr_seg_length(p);
+	// the keys this workgroup walks: the whole list, or one segment of it
+	const uint32_t n = MODE == 2 ? min(segL, n_all - seg * segL) : n_all;
+	const uint64_t* gk = p.keys + p.tile_off[vt] + (MODE == 2 ? (size_t)seg * segL : (size_t)0);
 	(void)vP; (void)recq;
 	const float4* rec = f.recA + (size_t)v * f.ab_view;
 	const float4* rq = f.recQ + (size_t)v * f.q_view;
@@ -4296,7 +4332,8 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 	float T = 1.0f;
 	double Cg = 0.0;
 	bool done = !inside;
-	fr_strip_pass<BW, BH, 0>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done,
+	auto pass1 = [&](const uint64_t* keys, uint32_t nk) {
+	fr_strip_pass<BW, BH, 0>(keys, nk, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done,
 		[&](uint32_t, uint32_t, unsigned long long emask) {
 			unsigned long long mask = fr_wave_transpose64(emask, lane);
 			if (done) mask = 0ull;
@@ -4312,11 +4349,43 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 				if (fr_prefix_update(g, b4.w, T, Cg, con)) { mask = 0ull; done = true; }
 			}
 		});
-	const double X = Cg + (double)(T * (p.bg[0] + p.bg[1] + p.bg[2]));
+	};
+	double X;
+	const size_t px_slot = vt * (size_t)FR_THREADS + (size_t)tid;               // this pixel in [V T][256] arrays
+	if constexpr (MODE == 0) { pass1(gk, n); X = Cg + (double)(T * (p.bg[0] + p.bg[1] + p.bg[2])); }
+	else if constexpr (MODE == 1)
+	{
+		// segment after segment; the state at the start of a segment is what pass 2 of that segment starts from
+		__shared__ uint32_t s_base;
+		const uint32_t nseg = (n + segL - 1u) / segL;                   // (<= tiles <= FR_SEG_TILES: L is at least the mean list length)
+		if (tid == 0 && nseg) s_base = atomicAdd(&sg.list[0], nseg);
+		__syncthreads();
+		const uint32_t e0 = nseg ? s_base : 0u;
+		for (uint32_t s0 = 0, sI = 0; s0 < n; s0 += segL, sI++)
+		{
+			if (tid == 0) sg.list[1 + e0 + sI] = ((uint32_t)vt << 12) | sI;
+			const size_t o = (size_t)(e0 + sI) * (size_t)FR_THREADS + (size_t)tid;
+			sg.snapT[o] = done ? -1.0f : T;
+			sg.snapC[o] = Cg;
+			pass1(gk + s0, min(segL, n - s0));
+		}
+		sg.X[px_slot] = Cg + (double)(T * (p.bg[0] + p.bg[1] + p.bg[2]));
+		return;
+	}
+	else
+	{
+		X = sg.X[px_slot];
+		{
+			const size_t o = (size_t)blockIdx.x * (size_t)FR_THREADS + (size_t)tid;
+			const float t0 = sg.snapT[o];
+			T = t0 < 0.f ? 1.0f : t0;                // (a finished pixel walks nothing: its T is never read)
+			done = t0 < 0.f || !inside;
+			Cg = sg.snapC[o];
+		}
+	}
 
 	// ---- pass 2: the squares
-	T = 1.0f; Cg = 0.0;
-	done = !inside;
+	if constexpr (MODE == 0) { T = 1.0f; Cg = 0.0; done = !inside; }
 	const float dL2 = f.dL * f.dL;
 	float* dst = f.out_H + (size_t)v * f.outH_stride;
 	// one (pixel, candidate) pair: replays the recurrences and returns the pair's four squared columns (zero when it does not contribute)
@@ -6279,7 +6348,7 @@ static int fr_debug_mode()
 
 #define FR_MAX_GROUPS 4              // view groups of one fr_fisher_views call (fr_pick_groups)
 struct FrFisherLayout {
-	size_t radii, vis_n, splat, recq, slot_idx, packed, mt, grp, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, w2c_inv, status, keys, fallback, total;
+	size_t radii, vis_n, splat, recq, slot_idx, packed, mt, grp, big_list, view_work, view_perm, blk_base, cov3D, tile_cnt, tile_off, tile_fill, tile_scores, w2c_inv, status, keys, fallback, seg_T, seg_C, seg_X, seg_list, total;
 	size_t PV;                   // slots per view of the compact records: projection workgroups * 256 G (>= P)
 };
 static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t V, int64_t max_rendered, int columns)
@@ -6316,6 +6385,12 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	const size_t R = (size_t)(max_rendered > 0 ? max_rendered : 1);
 	L.keys = o; o = fr_align(o + R * 8);
 	L.fallback = o; o = fr_align(o + (size_t)(V * T));
+	// out_H launches of few views (k_fisher_tile_v3h<.., 1 / 2>): the pixels' state at the segment boundaries of their tile lists
+	const size_t seg_tiles = (size_t)(V * T <= FR_SEG_TILES ? V * T : 0);
+	L.seg_T = o; o = fr_align(o + 2 * seg_tiles * FR_THREADS * 4);
+	L.seg_C = o; o = fr_align(o + 2 * seg_tiles * FR_THREADS * 8);
+	L.seg_X = o; o = fr_align(o + seg_tiles * FR_THREADS * 8);
+	L.seg_list = o; o = fr_align(o + (2 * seg_tiles + 1) * 4);
 	L.total = o;
 	return L;
 }
@@ -6368,7 +6443,7 @@ static void fr_launch_fisher_v3(FrParams& p, FrFisherArgs f, float4* recq, hipSt
 }
 
 // out_H mode with 4 columns and a constant upstream gradient: two front-to-back passes over the records
-static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, hipStream_t s)
+static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, FrSegArgs sg, hipStream_t s)
 {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_prof_on)
@@ -6376,7 +6451,15 @@ static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, hipS
 		(void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
 		(void)hipEventRecord(ev0, s);
 	}
-	hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq);
+	if (sg.snapT && p.T * p.V <= FR_SEG_TILES)
+	{
+		// few views: pass 1 per tile with the pixels' state saved at every segment boundary, pass 2 per (tile, segment)
+		(void)hipMemsetAsync(sg.list, 0, 4, s);
+		hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 1>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
+		hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 2>), dim3(2 * p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
+	}
+	else
+	hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 0>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);
@@ -6628,7 +6711,14 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 			tile_join.on = true;
 		}
 		if (v3) fr_launch_fisher_v3(pg, fg, pl.ra.recq, ts);
-		else if (v3h) fr_launch_fisher_v3h(pg, fg, pl.ra.recq, ts);
+		else if (v3h)
+		{
+			FrSegArgs sg;
+			sg.snapT = (float*)(ws + L.seg_T); sg.snapC = (double*)(ws + L.seg_C); sg.X = (double*)(ws + L.seg_X);
+			sg.list = (uint32_t*)(ws + L.seg_list);
+			if (pg.V * pg.T > FR_SEG_TILES) sg.snapT = nullptr;
+			fr_launch_fisher_v3h(pg, fg, pl.ra.recq, sg, ts);
+		}
 		else if (v3g) fr_launch_fisher_v3g(pg, fg, fc->columns, fc->dL_dpix_image != nullptr, ts);
 		else if (fc->columns == 4) fr_launch_fisher<4>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
 		else fr_launch_fisher<11>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
