@@ -4258,25 +4258,26 @@ __device__ __forceinline__ void fr_strip_pass(const uint64_t* __restrict__ gk, u
 
 // MODE 0: one workgroup per (tile, view) walks the whole list twice (many views: the grid fills the chip).
 // MODE 1 / 2 -- FEW views (compute_Hessian of one pose, the tester's per-path-step call: 256 tiles on 256 CUs, the time set by the
-// longest list): the lists are cut into segments of L keys, L = the launch's mean list length (status[0] / tiles, at least 256), so
-// that there are at most 2 x tiles segments in all.  MODE 1 is pass 1 alone, segment after segment; it enters the tile's segments in
+// longest list): the lists are cut into segments of L keys, L = a third of the launch's mean list length (status[0] / tiles; at least
+// 256), so that there are at most 4 x tiles segments in all -- the 1024 workgroups the chip holds of this kernel when one view is scored.  MODE 1 is pass 1 alone, segment after segment; it enters the tile's segments in
 // a work list and leaves every pixel's state {T, colour prefix, finished} at each segment's start, plus the pixel's X.  MODE 2 is
-// pass 2 of ONE segment per workgroup (grid = 2 x tiles; a workgroup beyond the list leaves -- an empty workgroup still costs its
+// pass 2 of ONE segment per workgroup (grid = 4 x tiles; a workgroup beyond the list leaves -- an empty workgroup still costs its
 // dispatch, ~50 ns, which is why the grid is not tiles x the longest list's segments), started from the saved state.  Pass 1 stays sequential per tile: the transmittance chain T <- T (1 - alpha) is rounded
 // at every step and its 1e-4 cut decides who contributes, so no segment can know its start state before its predecessors have run --
 // but pass 1 is the light pass (two ds_read_b128 and ~30 instructions per pair, no accumulators), pass 2 the heavy one.  A pixel's
 // pairs go through exactly the arithmetic of MODE 0, in the same order.
+#define FR_SEG_PER_TILE 4            // work-list entries per tile at most (L = a third of the mean list length)
 #define FR_SEG_TILES 1024             // (view, tile) pairs up to which an out_H launch cuts its lists into segments (4 views at 256 x 256)
 struct FrSegArgs {
-	float* snapT;                // [2 V T][256]: T at the start of work-list entry e (negative: the pixel is finished)
-	double* snapC;               // [2 V T][256]: colour prefix there
+	float* snapT;                // [4 V T][256]: T at the start of work-list entry e (negative: the pixel is finished)
+	double* snapC;               // [4 V T][256]: colour prefix there
 	double* X;                   // [V T][256]
 	uint32_t* list;              // [0] = entries (zeroed by the launcher), [1 + e] = (view * T + tile) << 12 | segment of the tile
 };
 __device__ __forceinline__ uint32_t fr_seg_length(const FrParams& p)
 {
 	const uint32_t tiles = (uint32_t)(p.V * p.T);
-	const uint32_t L = (((uint32_t)p.status[0] + tiles - 1u) / tiles + 63u) & ~63u;     // sum over tiles of ceil(n / L) <= 2 tiles
+	const uint32_t L = (((uint32_t)p.status[0] + 3u * tiles - 1u) / (3u * tiles) + 63u) & ~63u;     // sum over tiles of ceil(n / L) <= FR_SEG_PER_TILE tiles
 	return L < 256u ? 256u : L;
 }
 template <int BW, int BH, int MODE = 0>
@@ -6387,10 +6388,10 @@ static FrFisherLayout fr_fisher_layout(int64_t P, int64_t W, int64_t H, int64_t 
 	L.fallback = o; o = fr_align(o + (size_t)(V * T));
 	// out_H launches of few views (k_fisher_tile_v3h<.., 1 / 2>): the pixels' state at the segment boundaries of their tile lists
 	const size_t seg_tiles = (size_t)(V * T <= FR_SEG_TILES ? V * T : 0);
-	L.seg_T = o; o = fr_align(o + 2 * seg_tiles * FR_THREADS * 4);
-	L.seg_C = o; o = fr_align(o + 2 * seg_tiles * FR_THREADS * 8);
+	L.seg_T = o; o = fr_align(o + FR_SEG_PER_TILE * seg_tiles * FR_THREADS * 4);
+	L.seg_C = o; o = fr_align(o + FR_SEG_PER_TILE * seg_tiles * FR_THREADS * 8);
 	L.seg_X = o; o = fr_align(o + seg_tiles * FR_THREADS * 8);
-	L.seg_list = o; o = fr_align(o + (2 * seg_tiles + 1) * 4);
+	L.seg_list = o; o = fr_align(o + (FR_SEG_PER_TILE * seg_tiles + 1) * 4);
 	L.total = o;
 	return L;
 }
@@ -6456,7 +6457,7 @@ static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, FrSe
 		// few views: pass 1 per tile with the pixels' state saved at every segment boundary, pass 2 per (tile, segment)
 		(void)hipMemsetAsync(sg.list, 0, 4, s);
 		hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 1>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
-		hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 2>), dim3(2 * p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
+		hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 2>), dim3(FR_SEG_PER_TILE * p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
 	}
 	else
 	hipLaunchKernelGGL((k_fisher_tile_v3h<16, 4, 0>), dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p, f, (const float4*)recq, sg);
