@@ -6688,7 +6688,7 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 		pg.vis_count = p.vis_count ? p.vis_count + v0 : nullptr;
 		pg.num_rendered = p.num_rendered ? p.num_rendered + v0 : nullptr;
 		FrScorerPlan pl = plan;
-		pl.skip_pack = gi > 0;
+		pl.skip_pack = gi > 0 || (fc->reuse_static != 0 && compact);      // (the caller vouches that the workspace holds this call's static records)
 		if (pl.ra.hinv_stride) pl.ra.H_inv = plan.ra.H_inv + (size_t)v0 * plan.ra.hinv_stride;
 		pl.ra.recq = plan.ra.recq + (size_t)v0 * rec_view * 4;
 		if (pl.ra.comp) pl.ra.comp = plan.ra.comp + (size_t)v0 * L.PV * rstride;

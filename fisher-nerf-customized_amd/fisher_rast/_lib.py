@@ -62,6 +62,7 @@ class FisherCfg(ctypes.Structure):
         ("dL_image_view_stride", ctypes.c_int64),
         ("tile_capacity", ctypes.c_int32),
         ("poses_are_c2w", ctypes.c_int32),
+        ("reuse_static", ctypes.c_int32),
         ("order", ctypes.c_void_p),
     ]
 

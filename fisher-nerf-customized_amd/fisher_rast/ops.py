@@ -270,6 +270,7 @@ class FisherScorer:
         self.proj = _prep(raster_settings.projmatrix, d)
         self.campos = _prep(raster_settings.campos, d)
         self._ws = {}
+        self._static_key, self._static_hinv = None, None
         self.per_view_capacity = max(int(0.75 * self.P), 1 << 16)
         # Fixed key segments (fr_fisher_cfg.tile_capacity): every (view, tile) owns `tile_capacity` key slots, the projection
         # kernel places the keys itself and the scan / scatter kernels drop out of the launch sequence.  16384 keys (the largest
@@ -369,6 +370,14 @@ class FisherScorer:
         fc.out_vis_count = vis.data_ptr()
         fc.out_num_rendered = nr.data_ptr()
         fc.order = self.order.data_ptr() if self.order is not None else None
+        # the per-Gaussian static records (means, cov3D, colours, shared H_inv rows) are packed into the workspace by every call; a call
+        # that finds there what it would write -- same workspace and layout, same shared H_inv tensor in the same version (this scorer's
+        # Gaussians never change) -- skips that kernel (fr_fisher_cfg.reuse_static)
+        # (the H_inv TENSOR is held on to: a fresh tensor of a later call can then not land on its address and pass for it)
+        shared = None if (H_inv is None or H_inv_per_view) else H_inv
+        skey = (ws.data_ptr(), ws.numel(), V, max_rendered, fc.tile_capacity, None if shared is None else shared._version)
+        fc.reuse_static = 1 if (self._static_key == skey and self._static_hinv is shared) else 0
+        self._static_key, self._static_hinv = skey, shared
         with torch.cuda.device(d):
             _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
                                                 ws.data_ptr(), ws.numel(), max_rendered,

@@ -180,6 +180,11 @@ typedef struct fr_fisher_cfg {
 	                               fills itself -- no scan dependency and no scatter kernel; needs n_views * tiles * tile_capacity
 	                               <= max_rendered (and < 2^32).  A tile with more instances than that: overflow, status[3] = 1. */
 	int32_t poses_are_c2w;      /* 1: `w2c` holds camera-to-world poses; the library inverts them (one small kernel) */
+	int32_t reuse_static;       /* 1: THIS workspace still holds the per-Gaussian static records the call would build -- the previous
+	                               fr_fisher_views call on it (ordered before this one on the stream) had the same Gaussians, the same
+	                               shared H_inv rows (or none / per-view ones), the same columns, order, n_views and max_rendered -- so
+	                               the packing kernel is skipped.  A planner scores hundreds of pose batches against one map and one
+	                               H_inv (tester_gaussians_navigation.py:1684-1705); the caller vouches for the sameness. */
 	const uint32_t* order;      /* device [P] or null: a permutation of 0..P-1 -- the order in which the Gaussians are laid out and
 	                               processed inside the call (fr_spatial_order: Morton order of the means).  Purely a layout
 	                               hint: every input and output keeps the caller's indexing (H_inv rows, out_H rows), the contributor

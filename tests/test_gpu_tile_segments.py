@@ -176,3 +176,36 @@ def test_camera_to_world_poses_are_inverted_by_the_library(scene, gpu):
     got = sc.launch(c2w, H_inv=hinv, poses_are_c2w=True)
     assert int(got["status"].cpu()[1]) == 0
     assert rel_err(got["scores"].cpu().numpy(), want.cpu().numpy()) < 2e-5
+
+
+def test_static_records_are_reused_only_when_nothing_changed(scene, gpu):
+    """fr_fisher_cfg.reuse_static: a second call with the same shared H_inv tensor (same version) skips the packing kernel and gives the
+    same scores bit for bit; an in-place change of H_inv, another H_inv tensor, another number of views or a grown workspace packs again
+    -- checked through the scores (a stale record would give the old H_inv's scores)."""
+    s = scene
+    sc = _scorer(s, gpu, 4, 16384)
+    h1 = s["H_inv"][:, :4].contiguous()
+    w = s["w2c"]
+    a = sc.run(w, H_inv=h1)["scores"].clone()
+    assert sc._static_key is not None
+    b = sc.run(w, H_inv=h1)["scores"].clone()                     # reuse
+    assert torch.equal(a, b)
+    h1.mul_(2.0)                                                  # in place: the version changes
+    c = sc.run(w, H_inv=h1)["scores"].clone()
+    assert torch.allclose(c, 2.0 * a, rtol=1e-6)
+    h2 = (h1 * 0.5)                                               # another tensor (possibly at a recycled address)
+    d = sc.run(w, H_inv=h2)["scores"].clone()
+    assert torch.allclose(d, a, rtol=1e-6)
+    del h2
+    h3 = torch.full_like(h1, 0.25)
+    e = sc.run(w[:8], H_inv=h3)["scores"].clone()                 # fewer views: another layout
+    f = sc.run(w[:8], H_inv=torch.full_like(h1, 0.5))["scores"].clone()
+    assert torch.allclose(f, 2.0 * e, rtol=1e-6)
+    # out_H mode after a score call and back: H_inv rows are not part of the out_H records' static part, but the layout key changes
+    Ht = torch.zeros((s["P"], 4), device=gpu)
+    sc.run(w[:8], out_H=Ht)
+    Ht2 = torch.zeros((s["P"], 4), device=gpu)
+    sc.run(w[:8], out_H=Ht2)                                      # reuse in the out_H mode
+    assert rel_err(Ht2.cpu().numpy(), Ht.cpu().numpy()) < 1e-5 and float(Ht.max()) > 0
+    g = sc.run(w[:8], H_inv=h3)["scores"].clone()
+    assert torch.allclose(g, e, rtol=1e-6)
