@@ -3754,6 +3754,9 @@ void k_fisher_tile_v4(FrParams p, FrFisherArgs f)
 template <int N>
 __device__ __forceinline__ bool fr_quad_combine(int key, float (&h)[N], int lane)
 {
+#ifdef FR_NO_QUAD_COMBINE          // (A/B builds: tools/build_variant.sh noqc -DFR_NO_QUAD_COMBINE)
+	return key >= 0;
+#endif
 	const int q = lane & 3;
 	float add[N];
 #pragma unroll
