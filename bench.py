@@ -182,11 +182,23 @@ def api_latencies(dev, raw_params, W, H, seed, V):
     slam.pose_eval(poses)
     torch.cuda.synchronize()
     reps = 5
+    # every call recomputes H_train, as the reference does (the product keeps 1 / (H_train + reg) while map and keyframes are unchanged)
+    slam.CACHE_H_TRAIN = False
+    slam.pose_eval(poses)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         scores, _ = slam.pose_eval(poses)
     torch.cuda.synchronize()
     t_pe = (time.perf_counter() - t0) / reps
+    slam.CACHE_H_TRAIN = True
+    slam.pose_eval(poses)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        scores, _ = slam.pose_eval(poses)
+    torch.cuda.synchronize()
+    t_pe_kept = (time.perf_counter() - t0) / reps
     w2cs = synthetic.invert_rigid(torch.stack(poses[:16]).cpu()).to(dev)
     slam.compute_Hessian(w2cs[0], return_points=True)
     torch.cuda.synchronize()
@@ -195,8 +207,9 @@ def api_latencies(dev, raw_params, W, H, seed, V):
         h = slam.compute_Hessian(w, return_points=True)
         float(h[0, 0])                                          # the caller reads the result (tester 1690-1695)
     t_ch = (time.perf_counter() - t0) / len(w2cs)
-    return (dict(ms_per_call=1e3 * t_pe, views=V, keyframes=16,
-                 what="GaussianSLAM.pose_eval(poses): H_train over the keyframes + all candidate scores, result on the host"),
+    return (dict(ms_per_call=1e3 * t_pe, ms_per_call_h_train_kept=1e3 * t_pe_kept, views=V, keyframes=16,
+                 what="GaussianSLAM.pose_eval(poses): H_train over the keyframes + all candidate scores, result on the host; "
+                      "`h_train_kept`: repeated calls on an unchanged map and keyframe set (1 / (H_train + reg) is kept)"),
             1e3 * t_ch)
 
 

@@ -165,6 +165,20 @@ class FisherOps:
         scorer.run(w2cs, out_H=H_train)
         return H_train
 
+    def _keyframe_key(self):
+        """The keyframe poses as (tensor objects, their versions), or None when they cannot be followed (not device tensors).  The
+        cache holds on to the tensor OBJECTS, so a later tensor cannot take a freed one's identity."""
+        if not getattr(self, "CACHE_H_TRAIN", True):
+            return None
+        ts = [kf['est_w2c'] for kf in self.keyframe_list]
+        if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in ts):
+            return None
+        return ts, tuple(t._version for t in ts)
+
+    @staticmethod
+    def _same_keyframes(a, b):
+        return a is not None and b is not None and len(a[0]) == len(b[0]) and a[1] == b[1] and all(x is y for x, y in zip(a[0], b[0]))
+
     def gs_pts_cnt(self, random_gaussian_params=None):
         """ API Setting """
         return 1
@@ -189,14 +203,28 @@ class FisherOps:
         scorer = self._scorer(extra)
         V, K = int(c2w.shape[0]), len(self.keyframe_list)
         if 0 < K and max(V, K) <= scorer.max_views_per_launch():
-            kf = self._stack_poses([kf['est_w2c'] for kf in self.keyframe_list])
-            H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
-            r1 = scorer.launch(kf, out_H=H_train)
-            # (the poses go in as they are: the library inverts them -- one kernel in place of torch.linalg.inv's dozen launches)
-            r2 = scorer.launch(c2w, H_inv=torch.reciprocal(H_train + self.H_TRAIN_REG), poses_are_c2w=True)
-            host = torch.cat([r1["status"], r2["status"], r2["scores"].view(torch.int32)]).cpu()      # the one sync
-            if int(host[1]) == 0 and int(host[5]) == 0:
-                return host[8:].view(torch.float32).clone(), c2w
+            # H_train is a function of (map, keyframe poses): a planner calls pose_eval for batch after batch of candidates between two
+            # mapping steps, so 1 / (H_train + reg) is kept while neither has changed (the scorer is per map version already; the
+            # keyframe poses are followed by tensor identity + version -- poses that are not device tensors are not followed, no reuse)
+            kkey = self._keyframe_key()
+            cached = getattr(self, "_h_inv_cache", None)
+            if cached is not None and cached[0] is scorer and self._same_keyframes(cached[1], kkey):
+                r2 = scorer.launch(c2w, H_inv=cached[2], poses_are_c2w=True)
+                host = torch.cat([r2["status"], r2["scores"].view(torch.int32)]).cpu()
+                if int(host[1]) == 0:
+                    return host[4:].view(torch.float32).clone(), c2w
+            else:
+                kf = self._stack_poses([kf['est_w2c'] for kf in self.keyframe_list])
+                H_train = torch.zeros((scorer.P, self.FISHER_COLUMNS), dtype=torch.float32, device=self._device())
+                r1 = scorer.launch(kf, out_H=H_train)
+                # (the poses go in as they are: the library inverts them -- one kernel in place of torch.linalg.inv's dozen launches)
+                H_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
+                r2 = scorer.launch(c2w, H_inv=H_inv, poses_are_c2w=True)
+                host = torch.cat([r1["status"], r2["status"], r2["scores"].view(torch.int32)]).cpu()      # the one sync
+                if int(host[1]) == 0 and int(host[5]) == 0:
+                    self._h_inv_cache = (scorer, kkey, H_inv) if kkey is not None else None
+                    return host[8:].view(torch.float32).clone(), c2w
+            self._h_inv_cache = None
             # the tile-instance buffer was too small (nothing was accumulated or scored): the growing path below repeats both
         H_train = self.compute_H_train(extra)
         H_train_inv = torch.reciprocal(H_train + self.H_TRAIN_REG)
@@ -215,7 +243,7 @@ class FisherOps:
         """Graft the accelerated methods onto the reference's class.  `patch_get_loss=True` also replaces the
         module-level `get_loss` of the module `target_cls` lives in by the fused-render form (`make_get_loss`); off by default --
         a caller that only wants the Fisher scorer keeps the reference's training step untouched."""
-        for name in ("_device", "_as_w2c", "_stack_poses", "_scorer", "_scorer_key", "_PARAM_KEYS", "compute_Hessian", "compute_H_train",
+        for name in ("_device", "_as_w2c", "_stack_poses", "_scorer", "_scorer_key", "_keyframe_key", "_same_keyframes", "_PARAM_KEYS", "compute_Hessian", "compute_H_train",
                      "pose_eval", "path_scores"):
             setattr(target_cls, name, getattr(cls, name))
         # the module-level get_loss of the reference (gaussian.py:184-297), rebuilt around the reference module's own

@@ -187,6 +187,43 @@ def test_scorer_is_reused_until_the_map_changes(config1, gpu):
     assert slam._scorer() is not b
 
 
+def test_pose_eval_keeps_h_train_until_map_or_keyframes_change(config1, gpu):
+    """pose_eval recomputes H_train over the keyframes in the reference on every call (gaussian.py:1354-1375); here 1 / (H_train + reg)
+    is kept while the map and the keyframe poses are what they were: the repeated call must give the same scores, and a new keyframe,
+    an in-place change of a keyframe pose or of the map must be seen."""
+    import models.gaussian_slam as mgs
+    c = config1
+    slam = mgs.GaussianSLAM(params={k: v.clone() for k, v in c["params"].items()}, intrinsics=c["K"], width=c["W"], height=c["H"], device=gpu)
+    for w in c["kf_w2c"][:2]:
+        slam.add_keyframe(w.clone())
+    poses = [p.to(gpu) for p in c["c2w"][:4]]
+    s0, _ = slam.pose_eval(poses)
+    assert slam._h_inv_cache is not None
+    held = slam._h_inv_cache[2]
+    s1, _ = slam.pose_eval(poses)
+    assert slam._h_inv_cache[2] is held and torch.equal(s0, s1)                 # reused, same scores
+    # the uncached route gives the same numbers (H_train sums float atomics: equal to rounding)
+    slam.CACHE_H_TRAIN = False
+    s2, _ = slam.pose_eval(poses)
+    slam.CACHE_H_TRAIN = True
+    assert torch.allclose(s2, s0, rtol=1e-5)
+    slam.add_keyframe(c["kf_w2c"][2].clone())                                     # a new keyframe
+    s3, _ = slam.pose_eval(poses)
+    assert slam._h_inv_cache[2] is not held and not torch.allclose(s3, s0, rtol=1e-3)
+    held = slam._h_inv_cache[2]
+    slam.keyframe_list[0]['est_w2c'][0, 3] += 0.25                                # a keyframe pose refined in place
+    s4, _ = slam.pose_eval(poses)
+    assert slam._h_inv_cache[2] is not held and not torch.equal(s4, s3)
+    held = slam._h_inv_cache[2]
+    slam.params["logit_opacities"].mul_(0.9)                                      # an optimiser step on the map
+    s5, _ = slam.pose_eval(poses)
+    assert slam._h_inv_cache[2] is not held and not torch.equal(s5, s4)
+    # and against the two-step route of the reference's structure
+    Ht = slam.compute_H_train()
+    want = slam._scorer().run(torch.stack(poses), H_inv=torch.reciprocal(Ht + slam.H_TRAIN_REG), poses_are_c2w=True)["scores"].cpu()
+    assert torch.allclose(s5, want, rtol=1e-5)
+
+
 def test_per_view_weights_path_eval(config1, gpu):
     """H_inv_view_stride != 0: each view has its own weights (the planner's path evaluation, tester 1688-1705)."""
     c = config1

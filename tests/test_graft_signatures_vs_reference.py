@@ -22,7 +22,7 @@ TARGETS = [
 # what the product adds that the reference class does not have (helpers and new operators): allowed, but named here so that a
 # typo in a grafted name cannot hide as "new"
 NEW_IN_PRODUCT = {
-    "FisherOps": {"_device", "_as_w2c", "_stack_poses", "_scorer", "_scorer_key", "_PARAM_KEYS", "path_scores"},
+    "FisherOps": {"_device", "_as_w2c", "_stack_poses", "_scorer", "_scorer_key", "_keyframe_key", "_same_keyframes", "_PARAM_KEYS", "path_scores"},
     "ObjectFisherOps": {"_draw_probes", "_probe_rows", "_pose_probe_rows", "_flat_diag", "_diag_batch", "_diag_scores", "_block_columns",
                         "_visible_indices", "_block_scores"},
     "OccupancyOps": {"_fbe_point", "_ring_candidates", "generate_candidate_in_freespace", "_next_seed", "_eroded_free", "filter_candidates_in_freespace", "cells_of", "_occ_cfg",
