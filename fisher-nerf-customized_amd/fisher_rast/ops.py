@@ -376,13 +376,18 @@ class FisherScorer:
         # (the H_inv TENSOR is held on to: a fresh tensor of a later call can then not land on its address and pass for it)
         shared = None if (H_inv is None or H_inv_per_view) else H_inv
         skey = (ws.data_ptr(), ws.numel(), V, max_rendered, fc.tile_capacity, None if shared is None else shared._version)
-        fc.reuse_static = 1 if (self._static_key == skey and self._static_hinv is shared) else 0
-        self._static_key, self._static_hinv = skey, shared
+        if H_inv is not None and out_H is not None:
+            # scores AND diagonals in one call run the two-pass fall-back kernel, which packs its own static records and leaves the
+            # front end's {mean, trace} array unwritten: nothing of this call may be reused by the next one
+            skey = None
+        fc.reuse_static = 1 if (skey is not None and self._static_key == skey and self._static_hinv is shared) else 0
+        self._static_key, self._static_hinv = None, None            # (set again once the call has been enqueued without an error)
         with torch.cuda.device(d):
             _lib.check(self.lib.fr_fisher_views(ctypes.byref(self.cfg), ctypes.byref(self.g), ctypes.byref(fc),
                                                 ws.data_ptr(), ws.numel(), max_rendered,
                                                 status.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream)),
                        "fr_fisher_views")
+        self._static_key, self._static_hinv = skey, shared
         return dict(scores=scores, vis_count=vis, num_rendered=nr, status=status, n_views=V, _keep=(w2c, H_inv, dL_image))
 
     def run(self, w2c, H_inv=None, H_inv_per_view=False, out_H=None, out_H_per_view=False, dL_image=None, poses_are_c2w=False):

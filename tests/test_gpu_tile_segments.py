@@ -209,3 +209,13 @@ def test_static_records_are_reused_only_when_nothing_changed(scene, gpu):
     assert rel_err(Ht2.cpu().numpy(), Ht.cpu().numpy()) < 1e-5 and float(Ht.max()) > 0
     g = sc.run(w[:8], H_inv=h3)["scores"].clone()
     assert torch.allclose(g, e, rtol=1e-6)
+    # scores AND diagonals in one call (the two-pass fall-back: it leaves the front end's static arrays unwritten) must not be taken
+    # for a call whose static records can be reused -- on a FRESH scorer, so that nothing valid is left over from earlier calls
+    sc2 = _scorer(s, gpu, 4, 16384)
+    hv = torch.full((8, s["P"], 4), 0.25, device=gpu)
+    cur = torch.zeros((8, s["P"], 4), device=gpu)
+    both = sc2.run(w[:8], H_inv=hv, H_inv_per_view=True, out_H=cur, out_H_per_view=True)["scores"].clone()
+    assert torch.allclose(both, e, rtol=1e-5)
+    cur2 = torch.zeros((8, s["P"], 4), device=gpu)
+    sc2.run(w[:8], out_H=cur2, out_H_per_view=True)                # the records path right after it: must pack
+    assert rel_err(cur2.cpu().numpy(), cur.cpu().numpy()) < 1e-5 and float(cur2.sum(dim=(1, 2)).min()) > 0
