@@ -1794,11 +1794,135 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 	else fr_sort_wg_segment<8, 4>(skeys, gk, n, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_sort_part: the long lists of fixed key segments (FR_SORT_SMALL_KEYS < n <= part_max) are PARTITIONED before they are sorted.
+// A bitonic network over n keys runs log2(n_pad) (log2(n_pad) + 1) / 2 stages on every key -- 78 for 4096, 91 for 8192 -- and the
+// two long-list tiers cost 3x / 10x the time per key of the short-list tier (16 keys per lane, 1024-thread workgroups).  Here a
+// workgroup
+//   1  sorts a SAMPLE of 256 of the list's keys (every n/256-th; one wave, in registers) and takes NP - 1 of them as pivots, NP = the
+//      power of two that makes a part ~256-320 keys.  Pivots are full 64-bit keys (depth | slot), so runs of equal depth split too, and
+//      a sample follows the depth clusters of the walls a tile looks at (equal-width buckets do not: profiles/r04_e_split_sort.txt);
+//   2  classifies every key (binary search over the pivots: the part index is monotone in the key), counts the parts, scans;
+//   3  scatters the keys part by part into the UPPER half of the tile's segment (a fixed segment holds tile_capacity keys, the list
+//      uses n of them; the order inside a part is arbitrary);
+//   4  lets its four waves take the parts one after the other, each sorted by ONE wave in registers (up to 512 keys: the cheapest
+//      form of the network, 45 stages, no LDS, no barrier); a part that sampling left larger goes to the whole workgroup;
+//   5  moves the tile's offset to where the sorted list now stands.
+// Parts are ranges of the key order, so their concatenation is the sorted list: the same result as the bitonic tiers, which keep the
+// lists this kernel does not take (packed lists: no room; lists beyond part_max).
+#define FR_PART_SAMPLE 256
+#define FR_PART_MAXP 32
+__global__ __launch_bounds__(FR_THREADS) void k_sort_part(FrParams p, uint32_t part_max)
+{
+	__shared__ uint64_t skeys[FR_SORT_SMALL_KEYS];          // the workgroup-level sort of an oversized part
+	__shared__ uint64_t s_piv[FR_PART_MAXP];
+	__shared__ uint32_t s_cnt[FR_PART_MAXP], s_off[FR_PART_MAXP], s_cur[FR_PART_MAXP];
+	__shared__ uint32_t s_next;
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const uint32_t count = p.big_list[0];
+	for (uint32_t b = blockIdx.x; b < count; b += gridDim.x)
+	{
+		const size_t vt = p.big_list[16 + b];
+		const uint32_t n = p.tile_cnt[vt];
+		if (n > part_max) continue;                            // (uniform) a bitonic tier's list
+		uint64_t* gk = p.keys + p.tile_off[vt];
+		const uint32_t n_al = (n + 63u) & ~63u;
+		uint64_t* tmp = gk + n_al;
+		// parts of ~256-320 keys: NP = 8 (n <= 2560), 16 (<= 5120), 32
+		const uint32_t NP = n <= 2560u ? 8u : n <= 5120u ? 16u : 32u;
+		__syncthreads();                                       // the previous list's LDS is free
+		if (tid < FR_PART_MAXP) { s_cnt[tid] = 0u; s_cur[tid] = 0u; }
+		if (tid == 0) s_next = 0u;
+		// ---- 1: the sample, sorted by wave 0 (4 keys per lane)
+		if (tid < 64)
+		{
+			uint64_t key[4];
+#pragma unroll
+			for (int r = 0; r < 4; r++) key[r] = gk[(uint32_t)(((uint64_t)(uint32_t)(lane * 4 + r) * n) >> 8)];
+			fr_wave_stages<4, 8>(key, (uint32_t)FR_PART_SAMPLE, lane);
+			// pivot q (1 .. NP - 1) = sample element q * 256 / NP = register 0 of lane q * 64 / NP
+			const uint32_t step = 64u / NP;                      // 8, 4 or 2 lanes
+			if (((uint32_t)lane % step) == 0u && lane > 0) s_piv[(uint32_t)lane / step] = key[0];
+		}
+		__syncthreads();
+		auto part_of = [&](uint64_t k) -> uint32_t {
+			// number of pivots <= k (pivots ascending): binary search over NP - 1 entries, s_piv[1 .. NP - 1]
+			uint32_t lo = 0u;                                    // invariant: pivots 1 .. lo are <= k
+			for (uint32_t stepw = NP >> 1; stepw > 0u; stepw >>= 1)
+			{
+				const uint32_t mid = lo + stepw;
+				if (s_piv[mid] <= k) lo = mid;
+			}
+			return lo;
+		};
+		// ---- 2: count (eight keys per thread and trip: their loads and their searches in flight together)
+		constexpr int KB = 8;
+		for (uint32_t i0 = 0; i0 < n; i0 += KB * FR_THREADS)
+		{
+			uint64_t k[KB];
+#pragma unroll
+			for (int r = 0; r < KB; r++) { const uint32_t i = i0 + r * FR_THREADS + tid; k[r] = i < n ? gk[i] : ~0ull; }
+#pragma unroll
+			for (int r = 0; r < KB; r++) { const uint32_t i = i0 + r * FR_THREADS + tid; if (i < n) atomicAdd(&s_cnt[part_of(k[r])], 1u); }
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			uint32_t run = 0;
+			for (uint32_t q = 0; q < NP; q++) { s_off[q] = run; run += s_cnt[q]; }
+		}
+		__syncthreads();
+		// ---- 3: scatter
+		for (uint32_t i0 = 0; i0 < n; i0 += KB * FR_THREADS)
+		{
+			uint64_t k[KB];
+#pragma unroll
+			for (int r = 0; r < KB; r++) { const uint32_t i = i0 + r * FR_THREADS + tid; k[r] = i < n ? gk[i] : ~0ull; }
+#pragma unroll
+			for (int r = 0; r < KB; r++)
+			{
+				const uint32_t i = i0 + r * FR_THREADS + tid;
+				if (i < n) { const uint32_t q = part_of(k[r]); tmp[s_off[q] + atomicAdd(&s_cur[q], 1u)] = k[r]; }
+			}
+		}
+		__syncthreads();                                       // (the workgroup's own global stores, read back by its waves below)
+		// ---- 4: the parts, one wave each
+		for (;;)
+		{
+			uint32_t q = 0;
+			if (lane == 0) q = atomicAdd(&s_next, 1u);
+			q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+			if (q >= NP) break;
+			const uint32_t c = s_cnt[q];
+			uint64_t* pk = tmp + s_off[q];
+			if (c < 2u || c > 512u) continue;
+			if (c <= 64u) fr_sort_wave_segment<1>(pk, c, lane);
+			else if (c <= 128u) fr_sort_wave_segment<2>(pk, c, lane);
+			else if (c <= 256u) fr_sort_wave_segment<4>(pk, c, lane);
+			else fr_sort_wave_segment<8>(pk, c, lane);
+		}
+		__syncthreads();
+		// ... and what sampling left larger than a wave's 512 keys, by the whole workgroup (uniform: every thread reads the same counts)
+		for (uint32_t q = 0; q < NP; q++)
+		{
+			const uint32_t c = s_cnt[q];
+			if (c <= 512u) continue;
+			uint64_t* pk = tmp + s_off[q];
+			if (c <= 1024u) fr_sort_wg_segment<4, 4>(skeys, pk, c, tid);
+			else if (c <= (uint32_t)FR_SORT_SMALL_KEYS) fr_sort_wg_segment<8, 4>(skeys, pk, c, tid);
+			else fr_bitonic(pk, c, tid, FR_THREADS);
+			__syncthreads();
+		}
+		if (tid == 0) p.tile_off[vt] += n_al;                  // ---- 5
+	}
+}
+
 // Larger segments are listed by k_scan_tiles and sorted by two grid-stride kernels over that list:
 //   k_sort_mid_tiles : FR_SORT_SMALL_KEYS < n <= FR_SORT_MID_KEYS, 256 threads x 16 keys, 32 KiB of LDS
 //   k_sort_big_tiles : n > FR_SORT_MID_KEYS, 1024 threads x 8 or 16 keys, 128 KiB of LDS; beyond FR_SORT_BIG_KEYS the
 //                      LDS-resident form of the network runs on global memory (__syncthreads orders the workgroup's own accesses).
-__global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
+__global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p, uint32_t part_max)
 {
 	if (p.status[1]) return;
 	__shared__ uint64_t skeys[FR_SORT_MID_KEYS];
@@ -1808,7 +1932,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
 	{
 		const size_t vt = p.big_list[16 + b];
 		const uint32_t n = p.tile_cnt[vt];
-		if (n > (uint32_t)FR_SORT_MID_KEYS) continue;
+		if (n > (uint32_t)FR_SORT_MID_KEYS || n <= part_max) continue;        // (n <= part_max: k_sort_part's list)
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
 #ifdef FR_AB
@@ -1825,7 +1949,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_mid_tiles(FrParams p)
 	}
 }
 
-__global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
+__global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p, uint32_t part_max)
 {
 	if (p.status[1]) return;
 	__shared__ uint64_t skeys[FR_SORT_BIG_KEYS];
@@ -1835,7 +1959,7 @@ __global__ __launch_bounds__(1024) void k_sort_big_tiles(FrParams p)
 	{
 		const size_t vt = p.big_list[16 + b];
 		const uint32_t n = p.tile_cnt[vt];
-		if (n <= (uint32_t)FR_SORT_MID_KEYS) continue;
+		if (n <= (uint32_t)FR_SORT_MID_KEYS || n <= part_max) continue;
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		__syncthreads();
 		if (n > (uint32_t)FR_SORT_BIG_KEYS) fr_bitonic(gk, n, tid, 1024);
@@ -6012,15 +6136,33 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	const bool forked = want_fork && side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
 	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
 	if (forked) joins.forked(&side);
-	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p);
+	// Fixed key segments have room behind a list (tile_capacity keys per tile): lists of up to part_max keys are partitioned into
+	// wave-sized parts and sorted there (k_sort_part: after the short-list tier on the caller's stream); the two bitonic tiers keep what
+	// is longer, and everything long when the lists are packed.  FR_DEBUG_MODE=32 (rig): no partitioning.
+	uint32_t part_max = 0;
+	if (p.tile_cap >= 2u * (uint32_t)FR_SORT_SMALL_KEYS + 128u && fr_debug_mode() != 32)
+	{
+		part_max = p.tile_cap / 2u - 64u;
+		if (part_max > 8192u) part_max = 8192u;
+	}
+	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p, part_max);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;
+	const int mid_blocks = p.T * p.V < 2048 ? p.T * p.V : 2048;
 	// (the middle tier on a side stream of its own as well, all three tiers at once: 2.04 ms per 64-view step against 1.95 --
-	// the 256-thread tiers take each other's LDS and wave slots)
+	// the 256-thread tiers take each other's LDS and wave slots; k_sort_part beside the short-list tier on a stream of its own:
+	// 1.504-1.520 against 1.508-1.519 behind it, profiles/r04_q_ab_sort_part.txt)
 	hipLaunchKernelGGL(k_sort_tiles, dim3(p.T * p.V), dim3(FR_THREADS), 0, s, p);
 	if ((rc = fr_check_launch("k_sort_tiles"))) return rc;
-	const int mid_blocks = p.T * p.V < 2048 ? p.T * p.V : 2048;
-	hipLaunchKernelGGL(k_sort_mid_tiles, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p);
-	if ((rc = fr_check_launch("k_sort_mid_tiles"))) return rc;
+	if (part_max)
+	{
+		hipLaunchKernelGGL(k_sort_part, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p, part_max);
+		if ((rc = fr_check_launch("k_sort_part"))) return rc;
+	}
+	if (part_max < (uint32_t)FR_SORT_MID_KEYS)
+	{
+		hipLaunchKernelGGL(k_sort_mid_tiles, dim3(mid_blocks), dim3(FR_THREADS), 0, s, p, part_max);
+		if ((rc = fr_check_launch("k_sort_mid_tiles"))) return rc;
+	}
 	return joins.join();
 }
 

@@ -219,3 +219,51 @@ def test_static_records_are_reused_only_when_nothing_changed(scene, gpu):
     cur2 = torch.zeros((8, s["P"], 4), device=gpu)
     sc2.run(w[:8], out_H=cur2, out_H_per_view=True)                # the records path right after it: must pack
     assert rel_err(cur2.cpu().numpy(), cur.cpu().numpy()) < 1e-5 and float(cur2.sum(dim=(1, 2)).min()) > 0
+
+
+@pytest.mark.parametrize("P", [2300, 2600, 5200, 7000, 8192, 8300, 12000])
+def test_long_lists_in_fixed_segments_are_partitioned_and_sorted(gpu, P):
+    """k_sort_part: lists of 2049 .. 8128 keys in fixed segments of 16384 are split at sampled pivots into wave-sized parts, sorted behind the
+    list, and the tile's offset moves there.  One tile of a 48 x 48 view takes nearly every splat; depths cluster (three 'walls') and
+    a quarter of the splats are exact duplicates (runs of equal depth, split by the slot).  The segment must come out strictly
+    ascending with the list's own keys, and the scores must equal the packed-list path's (bitonic tiers) bit for bit."""
+    import ctypes
+    from fisher_rast import _lib
+    from fisher_rast.ops import FisherScorer
+    from fisher_rast.synthetic import intrinsics
+    from models.SLAM.utils.recon_helpers import setup_camera
+    rng = np.random.default_rng(P)
+    W = H = 48
+    z = np.concatenate([rng.normal(2.0, 0.004, P // 3), rng.normal(3.5, 0.004, P // 3), rng.uniform(1.0, 6.0, P - 2 * (P // 3))]).astype(np.float32)
+    u = rng.uniform(17.0, 30.0, P); v = rng.uniform(17.0, 30.0, P)
+    means = np.stack([(u - 23.5) / 24.0 * z, (v - 23.5) / 24.0 * z, z], 1).astype(np.float32)
+    means[P // 2:P // 2 + P // 4] = means[:P // 4]                       # duplicates
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    args = (t(means), t(rng.uniform(0, 1, (P, 3)).astype(np.float32)), t(np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1))),
+            t(rng.uniform(0.005, 0.02, P).astype(np.float32)), t(np.full((P, 3), 0.004, np.float32) * z[:, None]))
+    cam = setup_camera(W, H, intrinsics(W, H), np.eye(4), device=gpu)
+    w2c = torch.eye(4, device=gpu)[None].repeat(2, 1, 1)
+    w2c[1, 0, 3] = 0.01
+    Hi = (torch.rand((P, 4), generator=torch.Generator().manual_seed(1)) + 0.05).to(gpu)
+    fixed = FisherScorer(cam, *args, tile_capacity=16384)
+    packed = FisherScorer(cam, *args, tile_capacity=0)
+    a, b = fixed.run(w2c, H_inv=Hi), packed.run(w2c, H_inv=Hi)
+    assert fixed.tile_capacity == 16384
+    assert torch.equal(a["num_rendered"], b["num_rendered"]) and torch.equal(a["scores"], b["scores"]) and float(a["scores"].min()) > 0
+    # the sorted segments themselves
+    V, T = 2, 9
+    cap = V * fixed._keys_per_view()
+    off = (ctypes.c_size_t * 8)()
+    _lib.check(_lib.load().fr_fisher_workspace_layout(P, W, H, V, cap, 4, off), "layout")
+    ws = fixed._ws[0]
+    cnt = ws[off[0]:off[0] + V * T * 4].view(torch.int32).cpu().numpy().astype(np.int64)
+    toff = ws[off[1]:off[1] + V * T * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    keys = ws[off[2]:off[2] + cap * 8].view(torch.int64).cpu().numpy().view(np.uint64)
+    assert cnt.max() > 2048 or P < 2400
+    for i in range(V * T):
+        seg = keys[toff[i]:toff[i] + cnt[i]]
+        assert np.all(seg[1:] > seg[:-1]), (i, cnt[i])
+        moved = toff[i] != i * 16384
+        assert moved == (2048 < cnt[i] <= 16384 // 2 - 64), (i, cnt[i], toff[i])      # (a list and its parts must both fit the segment)
+        if moved:                                                   # the unsorted list still stands at the segment's start
+            assert np.array_equal(np.sort(keys[i * 16384:i * 16384 + cnt[i]]), seg)
