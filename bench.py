@@ -373,6 +373,7 @@ def main():
     ap.add_argument("--cpu-views", type=int, default=8, help="views of the 1-core CPU-baseline sample (0 = skip every side measurement)")
     ap.add_argument("--dump-scores", type=str, default="", help="rank 0 writes the gathered scores of the last step to this .npy (tests)")
     ap.add_argument("--seed", type=int, default=0, help="scene / pose seed (default: 2 on one GPU = configs[1], 3 on several = configs[2])")
+    ap.add_argument("--tile-capacity", type=int, default=-1, help="A/B: keys per fixed (view, tile) segment (FisherScorer's default when negative; 0 = packed lists)")
     ap.add_argument("--spatial-order", action="store_true", help="A/B: lay the Gaussians out along a Z-curve (fr_spatial_order; FisherScorer's option, off by default)")
     ap.add_argument("--synthetic-hinv", action="store_true",
                     help="tests: H_inv = seeded uniform weights instead of 1/(H_train+0.1) (H_train is accumulated with float atomics, "
@@ -441,7 +442,7 @@ def main():
         D.assert_replicated([act[k] for k in sorted(act)])
     cam = setup_camera(W, H, synthetic.intrinsics(W, H), np.eye(4), device=dev)
     scorer = FisherScorer(cam, *(act[k] for k in ("means3D", "rgb_colors", "rotations", "opacities", "scales")),
-                          columns=C, dL_dpix=1e-3, spatial_order=a.spatial_order)
+                          columns=C, dL_dpix=1e-3, spatial_order=a.spatial_order, **({} if a.tile_capacity < 0 else {"tile_capacity": a.tile_capacity}))
     w2c_all = synthetic.invert_rigid(synthetic.candidate_poses(V_total, seed)).to(dev)
     lo, hi = D.shard_bounds(V_total, rank, world)
     w2c = w2c_all[lo:hi].contiguous()

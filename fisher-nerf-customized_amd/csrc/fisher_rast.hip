@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 // A bitonic network over n keys runs log2(n_pad) (log2(n_pad) + 1) / 2 stages on every key -- 78 for 4096, 91 for 8192 -- and the
 // two long-list tiers cost 3x / 10x the time per key of the short-list tier (16 keys per lane, 1024-thread workgroups).  Here a
 // workgroup
-//   1  sorts a SAMPLE of 256 of the list's keys (every n/256-th; one wave, in registers) and takes NP - 1 of them as pivots, NP = the
+//   1  sorts a SAMPLE of 512 of the list's keys (every n/512-th; one wave, in registers) and takes NP - 1 of them as pivots, NP = the
 //      power of two that makes a part ~256-320 keys.  Pivots are full 64-bit keys (depth | slot), so runs of equal depth split too, and
 //      a sample follows the depth clusters of the walls a tile looks at (equal-width buckets do not: profiles/r04_e_split_sort.txt);
 //   2  classifies every key (binary search over the pivots: the part index is monotone in the key), counts the parts, scans;
@@ -1810,8 +1810,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 //   5  moves the tile's offset to where the sorted list now stands.
 // Parts are ranges of the key order, so their concatenation is the sorted list: the same result as the bitonic tiers, which keep the
 // lists this kernel does not take (packed lists: no room; lists beyond part_max).
-#define FR_PART_SAMPLE 256
-#define FR_PART_MAXP 32
+#define FR_PART_SAMPLE 512
+#define FR_PART_MAXP 64
 __global__ __launch_bounds__(FR_THREADS) void k_sort_part(FrParams p, uint32_t part_max)
 {
 	__shared__ uint64_t skeys[FR_SORT_SMALL_KEYS];          // the workgroup-level sort of an oversized part
@@ -1829,20 +1829,20 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_part(FrParams p, uint32_t p
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		const uint32_t n_al = (n + 63u) & ~63u;
 		uint64_t* tmp = gk + n_al;
-		// parts of ~256-320 keys: NP = 8 (n <= 2560), 16 (<= 5120), 32
-		const uint32_t NP = n <= 2560u ? 8u : n <= 5120u ? 16u : 32u;
+		// parts of ~256-320 keys: NP = 8 (n <= 2560), 16 (<= 5120), 32 (<= 10240), 64
+		const uint32_t NP = n <= 2560u ? 8u : n <= 5120u ? 16u : n <= 10240u ? 32u : 64u;
 		__syncthreads();                                       // the previous list's LDS is free
 		if (tid < FR_PART_MAXP) { s_cnt[tid] = 0u; s_cur[tid] = 0u; }
 		if (tid == 0) s_next = 0u;
-		// ---- 1: the sample, sorted by wave 0 (4 keys per lane)
+		// ---- 1: the sample, sorted by wave 0 (8 keys per lane)
 		if (tid < 64)
 		{
-			uint64_t key[4];
+			uint64_t key[8];
 #pragma unroll
-			for (int r = 0; r < 4; r++) key[r] = gk[(uint32_t)(((uint64_t)(uint32_t)(lane * 4 + r) * n) >> 8)];
-			fr_wave_stages<4, 8>(key, (uint32_t)FR_PART_SAMPLE, lane);
-			// pivot q (1 .. NP - 1) = sample element q * 256 / NP = register 0 of lane q * 64 / NP
-			const uint32_t step = 64u / NP;                      // 8, 4 or 2 lanes
+			for (int r = 0; r < 8; r++) key[r] = gk[(uint32_t)(((uint64_t)(uint32_t)(lane * 8 + r) * n) >> 9)];
+			fr_wave_stages<8, 9>(key, (uint32_t)FR_PART_SAMPLE, lane);
+			// pivot q (1 .. NP - 1) = sample element q * 512 / NP = register 0 of lane q * 64 / NP
+			const uint32_t step = 64u / NP;                      // 8, 4, 2 or 1 lanes
 			if (((uint32_t)lane % step) == 0u && lane > 0) s_piv[(uint32_t)lane / step] = key[0];
 		}
 		__syncthreads();
@@ -6132,7 +6132,10 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	// CU at most), so it goes to a side stream and runs underneath the two 256-thread tiers instead of after them.
 	FrSideStream& side = fr_side_stream();
 	// (a handful of views: the fork / join events cost more than the overlap gains -- one view 0.478 against 0.500 ms)
-	const bool want_fork = fr_debug_mode() != 7 && (!multi || p.V >= 8);   // FR_DEBUG_MODE=7: every sort tier on the caller's stream (timing ablation)
+	// (FR_DEBUG_MODE=7: every sort tier on the caller's stream -- timing ablation; fixed segments of 32768 keys and more: k_sort_part
+	// takes every list a segment can hold twice, the 1024-thread tier is left with lists beyond 16320 keys and runs behind it)
+	const bool part_all = p.tile_cap >= 32768u && fr_debug_mode() != 32;
+	const bool want_fork = fr_debug_mode() != 7 && (!multi || p.V >= 8) && !part_all;
 	const bool forked = want_fork && side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
 	const int big_blocks = p.T * p.V < 256 ? p.T * p.V : 256;
 	if (forked) joins.forked(&side);
@@ -6143,7 +6146,7 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 	if (p.tile_cap >= 2u * (uint32_t)FR_SORT_SMALL_KEYS + 128u && fr_debug_mode() != 32)
 	{
 		part_max = p.tile_cap / 2u - 64u;
-		if (part_max > 8192u) part_max = 8192u;
+		if (part_max > 16320u) part_max = 16320u;
 	}
 	hipLaunchKernelGGL(k_sort_big_tiles, dim3(big_blocks), dim3(1024), 0, forked ? side.stream : s, p, part_max);
 	if ((rc = fr_check_launch("k_sort_big_tiles"))) return rc;

@@ -247,7 +247,7 @@ class FisherScorer:
     MAX_KEY_BYTES_PER_VIEW = 512 << 20  # fixed key segments beyond this per view: packed lists instead (tile_capacity = 0)
 
     def __init__(self, raster_settings, means3D, rgb_colors, rotations, opacities, scales, columns: int = 4,
-                 dL_dpix: float = 1e-3, tile_capacity: int = 16384, spatial_order: bool = False):
+                 dL_dpix: float = 1e-3, tile_capacity: int = -1, spatial_order: bool = False):
         _need_gpu(means3D, "means3D")
         if columns not in (4, 11):
             raise ValueError("columns must be 4 or 11")
@@ -277,6 +277,10 @@ class FisherScorer:
         # list the in-LDS sort tiers take) x 8 B = 128 KiB per tile -- 32 MiB per 256 x 256 view of the 288 GB; a longer list
         # raises the overflow flag and `run` grows the segments, or goes back to packed lists where they would not fit.
         self.tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        # (default: 32768 keys -- the library then partitions every list of up to 16320 keys behind itself, k_sort_part, and the
+        # 1024-thread bitonic tier and its side stream only see longer lists -- or 16384 where that would pass the cap per view)
+        if tile_capacity < 0:
+            tile_capacity = 32768 if self.tiles * 32768 * 8 <= self.MAX_KEY_BYTES_PER_VIEW else 16384
         self.tile_capacity = int(tile_capacity)            # 0: packed key lists
         if self.tiles * self.tile_capacity * 8 > self.MAX_KEY_BYTES_PER_VIEW:
             self.tile_capacity = 0
@@ -300,7 +304,10 @@ class FisherScorer:
         one = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 1, self._keys_per_view(), self.columns))
         eight = int(self.lib.fr_fisher_workspace_bytes(self.P, self.W, self.H, 8, 8 * self._keys_per_view(), self.columns))
         per_view = max(1, (eight - one) // 7)
-        return max(1, int(self.WORKSPACE_BUDGET // per_view))
+        n = max(1, int(self.WORKSPACE_BUDGET // per_view))
+        if self.tile_capacity > 0:                      # fixed segments are addressed with 32-bit key offsets
+            n = max(1, min(n, ((1 << 32) - 1) // (self.tiles * self.tile_capacity)))
+        return n
 
     def _keys_per_view(self):
         return max(self.per_view_capacity, self.tiles * self.tile_capacity)

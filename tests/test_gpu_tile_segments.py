@@ -221,9 +221,10 @@ def test_static_records_are_reused_only_when_nothing_changed(scene, gpu):
     assert rel_err(cur2.cpu().numpy(), cur.cpu().numpy()) < 1e-5 and float(cur2.sum(dim=(1, 2)).min()) > 0
 
 
-@pytest.mark.parametrize("P", [2300, 2600, 5200, 7000, 8192, 8300, 12000])
-def test_long_lists_in_fixed_segments_are_partitioned_and_sorted(gpu, P):
-    """k_sort_part: lists of 2049 .. 8128 keys in fixed segments of 16384 are split at sampled pivots into wave-sized parts, sorted behind the
+@pytest.mark.parametrize("P,capacity", [(2300, 16384), (2600, 16384), (5200, 16384), (7000, 16384), (8192, 16384), (8300, 16384), (12000, 16384),
+                                        (5200, 32768), (8300, 32768), (12000, 32768), (16300, 32768), (17000, 32768)])
+def test_long_lists_in_fixed_segments_are_partitioned_and_sorted(gpu, P, capacity):
+    """k_sort_part: lists of 2049 .. capacity / 2 - 64 keys in fixed segments are split at sampled pivots into wave-sized parts, sorted behind the
     list, and the tile's offset moves there.  One tile of a 48 x 48 view takes nearly every splat; depths cluster (three 'walls') and
     a quarter of the splats are exact duplicates (runs of equal depth, split by the slot).  The segment must come out strictly
     ascending with the list's own keys, and the scores must equal the packed-list path's (bitonic tiers) bit for bit."""
@@ -245,10 +246,10 @@ def test_long_lists_in_fixed_segments_are_partitioned_and_sorted(gpu, P):
     w2c = torch.eye(4, device=gpu)[None].repeat(2, 1, 1)
     w2c[1, 0, 3] = 0.01
     Hi = (torch.rand((P, 4), generator=torch.Generator().manual_seed(1)) + 0.05).to(gpu)
-    fixed = FisherScorer(cam, *args, tile_capacity=16384)
+    fixed = FisherScorer(cam, *args, tile_capacity=capacity)
     packed = FisherScorer(cam, *args, tile_capacity=0)
     a, b = fixed.run(w2c, H_inv=Hi), packed.run(w2c, H_inv=Hi)
-    assert fixed.tile_capacity == 16384
+    assert fixed.tile_capacity == capacity
     assert torch.equal(a["num_rendered"], b["num_rendered"]) and torch.equal(a["scores"], b["scores"]) and float(a["scores"].min()) > 0
     # the sorted segments themselves
     V, T = 2, 9
@@ -263,7 +264,7 @@ def test_long_lists_in_fixed_segments_are_partitioned_and_sorted(gpu, P):
     for i in range(V * T):
         seg = keys[toff[i]:toff[i] + cnt[i]]
         assert np.all(seg[1:] > seg[:-1]), (i, cnt[i])
-        moved = toff[i] != i * 16384
-        assert moved == (2048 < cnt[i] <= 16384 // 2 - 64), (i, cnt[i], toff[i])      # (a list and its parts must both fit the segment)
+        moved = toff[i] != i * capacity
+        assert moved == (2048 < cnt[i] <= capacity // 2 - 64), (i, cnt[i], toff[i])      # (a list and its parts must both fit the segment)
         if moved:                                                   # the unsorted list still stands at the segment's start
-            assert np.array_equal(np.sort(keys[i * 16384:i * 16384 + cnt[i]]), seg)
+            assert np.array_equal(np.sort(keys[i * capacity:i * capacity + cnt[i]]), seg)
