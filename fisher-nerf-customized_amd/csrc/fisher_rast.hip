@@ -44,6 +44,7 @@
 #define FR_THREADS 256
 #define FR_G_MAX 32                  // upper bound of Gaussians per thread in the per-Gaussian kernels (FrParams::G)
 #define FR_MAX_LDS_TILES 4096        // tile histogram kept in LDS up to 1024x1024 images
+#define FR_PART_MIN_DEFAULT 2048     // fixed key segments: lists beyond this many keys are partitioned (k_sort_part) instead of sorted whole
 #define FR_SORT_SMALL_KEYS 2048      // per-tile segments up to this size: 16 KiB of LDS, many workgroups per CU
 #define FR_SORT_MID_KEYS 4096        // listed segments up to this size: 32 KiB of LDS, 256 threads
 #define FR_SORT_BIG_KEYS 16384       // up to this size: 128 KiB of LDS, one workgroup per CU; beyond: global memory
@@ -130,6 +131,7 @@ struct FrParams {
 	int VC;                      // views per preprocess workgroup
 	uint32_t tile_cap;           // 0: tile segments packed by the scan; > 0: every (view, tile) owns keys[(v T + t) tile_cap ...), filled by
 	                             // the projection kernel itself (k_preprocess_views_c<.., true>): no scan dependency, no scatter kernel
+	uint32_t small_max;          // lists of up to this many keys are sorted by k_sort_tiles, longer ones are listed for the other sort kernels
 	const uint32_t* order;       // [P] or null (fr_fisher_cfg.order): position -> the caller's Gaussian index; records modes of the multi-view front end only
 	int legacy_sort;             // FR_DEBUG_MODE=6: the LDS-resident sort network of round 1 (A/B runs)
 	int prefiltered;             // GaussianRasterizationSettings.prefiltered (single-view API): a near-plane-culled point raises status[3]
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
 // {total, a tile over its capacity, longest list, the same flag} by atomics on the zero-filled words; four tiles per thread.
 __global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int N, int T, uint32_t tile_cap,
                                                            int* __restrict__ status, uint32_t* __restrict__ big_list,
-                                                           uint32_t* __restrict__ view_work, uint32_t* __restrict__ view_perm, int ablate)
+                                                           uint32_t* __restrict__ view_work, uint32_t* __restrict__ view_perm, int ablate, uint32_t list_min)
 {
 	const int i0 = (blockIdx.x * FR_THREADS + threadIdx.x) * 4;
 	// per-view sums: in LDS first (a block's 1024 tiles span 1024 / T + 1 views at most), then one global add per view and block
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_tile_lists(const uint32_t* __res
 		off[i] = (uint32_t)i * tile_cap;
 		sum += c;
 		mx = c > mx ? c : mx;
-		if (c > (uint32_t)FR_SORT_SMALL_KEYS) big_list[16 + atomicAdd(&big_list[0], 1u)] = (uint32_t)i;
+		if (c > list_min) big_list[16 + atomicAdd(&big_list[0], 1u)] = (uint32_t)i;
 		if (view_work && c) atomicAdd(&s_vw[i / T - vfirst], c);
 	}
 	__syncthreads();
@@ -1768,7 +1770,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_tiles(FrParams p)
 	fr_tile_of_block(p, tile, v);
 	const size_t vt = (size_t)v * p.T + tile;
 	const uint32_t n = p.tile_cnt[vt];
-	if (n < 2 || n > (uint32_t)FR_SORT_SMALL_KEYS) return;
+	if (n < 2 || n > p.small_max) return;
 	uint64_t* gk = p.keys + p.tile_off[vt];
 #ifdef FR_AB
 	if (p.legacy_sort)
@@ -1829,8 +1831,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_sort_part(FrParams p, uint32_t p
 		uint64_t* gk = p.keys + p.tile_off[vt];
 		const uint32_t n_al = (n + 63u) & ~63u;
 		uint64_t* tmp = gk + n_al;
-		// parts of ~256-320 keys: NP = 8 (n <= 2560), 16 (<= 5120), 32 (<= 10240), 64
-		const uint32_t NP = n <= 2560u ? 8u : n <= 5120u ? 16u : n <= 10240u ? 32u : 64u;
+		// parts of ~256-320 keys: NP = 4 (n <= 1280), 8 (<= 2560), 16 (<= 5120), 32 (<= 10240), 64
+		const uint32_t NP = n <= 1280u ? 4u : n <= 2560u ? 8u : n <= 5120u ? 16u : n <= 10240u ? 32u : 64u;
 		__syncthreads();                                       // the previous list's LDS is free
 		if (tid < FR_PART_MAXP) { s_cnt[tid] = 0u; s_cur[tid] = 0u; }
 		if (tid == 0) s_next = 0u;
@@ -5934,6 +5936,7 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 	p.means3D = g->means3D; p.colors = g->colors_precomp; p.shs = g->shs; p.opac = g->opacities;
 	p.scales = g->scales; p.rots = g->rotations;
 	p.VC = 1;
+	p.small_max = FR_SORT_SMALL_KEYS;
 	p.order = nullptr;
 	p.legacy_sort = fr_debug_mode() == 6;
 	FR_ABL(p.ablate = fr_debug_mode();)
@@ -6104,9 +6107,15 @@ static int fr_bin_pipeline(FrParams& p, const fr_gaussians* g, hipStream_t s, co
 		hipLaunchKernelGGL(k_preprocess, gridP, dim3(FR_THREADS), hist_lds, s, p);
 		if ((rc = fr_check_launch("k_preprocess"))) return rc;
 	}
+	// fixed segments with room for k_sort_part: lists beyond `small_max` keys go to it (FR_PART_MIN, rig: A/B of the hand-over)
+	if (multi && p.tile_cap >= 2u * (uint32_t)FR_SORT_SMALL_KEYS + 128u && fr_debug_mode() != 32)
+	{
+		p.small_max = (uint32_t)FR_PART_MIN_DEFAULT;
+		FR_AB_ONLY({ const int e = fr_env_int("FR_PART_MIN"); if (e >= 512 && e <= FR_SORT_SMALL_KEYS) p.small_max = (uint32_t)e; })
+	}
 	if (multi && p.tile_cap)
 		hipLaunchKernelGGL(k_tile_lists, dim3((p.V * p.T + 4 * FR_THREADS - 1) / (4 * FR_THREADS)), dim3(FR_THREADS), 0, s, p.tile_cnt, p.tile_off, p.V * p.T, p.T,
-		                   p.tile_cap, p.status, p.big_list, p.view_work, p.view_perm, p.ablate);
+		                   p.tile_cap, p.status, p.big_list, p.view_work, p.view_perm, p.ablate, p.small_max);
 	else
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, p.tile_cnt, p.tile_off, p.tile_fill, p.V * p.T, p.T, p.V,
 	                   p.key_capacity, p.status, multi ? (int*)nullptr : p.num_rendered, p.big_list, p.view_work, p.view_perm);
