@@ -4594,8 +4594,9 @@ void k_fisher_tile_v3h(FrParams p, FrFisherArgs f, const float4* __restrict__ re
 // With z the colour sum cg of a splat becomes cgz = z . rgb per pair, X = z . (C_final + T_final bg), and nothing else
 // changes: dL_dalpha_i = T_i cgz_i - (X - Cgz_<=i) b_i.  Same two front-to-back passes, per-candidate double accumulators in LDS.
 // Replaces k_fisher_tile_v2<11, false, true> (199 VGPRs, a Jacobian chain per tile instance) on these paths.
-template <int NC, bool IMG>
-__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFisherArgs f)
+// MODE: as in k_fisher_tile_v3h (0 whole lists; few views: 1 = pass 1 segment after segment + the work list, 2 = pass 2 of one segment).
+template <int NC, bool IMG, int MODE = 0>
+__global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFisherArgs f, FrSegArgs sg)
 {
 	constexpr int NQ = NC >= 11 ? 11 : 5;          // float4 of the record behind {recA, recB}
 	constexpr int EF4 = 2 + NQ;
@@ -4606,15 +4607,27 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFi
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	uint32_t tile; int v;
-	fr_tile_of_block(p, tile, v);
+	uint32_t seg = 0;
+	if constexpr (MODE == 2)
+	{
+		if (blockIdx.x >= sg.list[0]) return;      // (uniform) beyond the work list
+		const uint32_t en = sg.list[1 + blockIdx.x];
+		const uint32_t vtb = en >> 12;
+		seg = en & 4095u;
+		v = (int)(vtb / (uint32_t)p.T); tile = vtb % (uint32_t)p.T;
+	}
+	else if constexpr (MODE == 1) { v = (int)(blockIdx.x / (uint32_t)p.T); tile = blockIdx.x % (uint32_t)p.T; }
+	else fr_tile_of_block(p, tile, v);
 	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
 	const uint32_t bx0 = tx * FR_BLOCK_X, by0 = ty * FR_BLOCK_Y + (uint32_t)wave * 4u;
 	const uint32_t pxx = bx0 + (uint32_t)(lane & 15), pxy = by0 + (uint32_t)(lane >> 4);
 	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
 	const float pfx = (float)pxx, pfy = (float)pxy;
 	const size_t vt = (size_t)v * p.T + tile;
-	const uint32_t n = p.tile_cnt[vt];
-	const uint64_t* gk = p.keys + p.tile_off[vt];
+	const uint32_t n_all = p.tile_cnt[vt];
+	const uint32_t segL = MODE == 0 ? 0u : fr_seg_length(p);
+	const uint32_t n = MODE == 2 ? min(segL, n_all - seg * segL) : n_all;
+	const uint64_t* gk = p.keys + p.tile_off[vt] + (MODE == 2 ? (size_t)seg * segL : (size_t)0);
 	const float4* rec = f.recA + (size_t)v * f.ab_view;
 	const float4* rq = f.recQ + (size_t)v * f.q_view;
 	const size_t sA = (size_t)f.ab_stride, sQ = (size_t)f.q_stride;
@@ -4652,13 +4665,44 @@ __global__ __launch_bounds__(FR_THREADS) void k_fisher_tile_v3g(FrParams p, FrFi
 			if (fr_prefix_update(g, cgz, T, Cg, con)) { mask = 0ull; done = true; }
 		}
 	};
-	fr_strip_pass<16, 4, NQ, decltype(pass1), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done, pass1);
 	const float bgz = IMG ? (z0 * p.bg[0] + z1 * p.bg[1] + z2 * p.bg[2]) : (p.bg[0] + p.bg[1] + p.bg[2]);
-	const double X = Cg + (double)(T * bgz);
+	double X;
+	const size_t px_slot = vt * (size_t)FR_THREADS + (size_t)tid;
+	if constexpr (MODE == 0)
+	{
+		fr_strip_pass<16, 4, NQ, decltype(pass1), EF4>(gk, n, rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done, pass1);
+		X = Cg + (double)(T * bgz);
+	}
+	else if constexpr (MODE == 1)
+	{
+		__shared__ uint32_t s_base;
+		const uint32_t nseg = (n + segL - 1u) / segL;
+		if (tid == 0 && nseg) s_base = atomicAdd(&sg.list[0], nseg);
+		__syncthreads();
+		const uint32_t e0 = nseg ? s_base : 0u;
+		for (uint32_t s0 = 0, sI = 0; s0 < n; s0 += segL, sI++)
+		{
+			if (tid == 0) sg.list[1 + e0 + sI] = ((uint32_t)vt << 12) | sI;
+			const size_t o = (size_t)(e0 + sI) * (size_t)FR_THREADS + (size_t)tid;
+			sg.snapT[o] = done ? -1.0f : T;
+			sg.snapC[o] = Cg;
+			fr_strip_pass<16, 4, NQ, decltype(pass1), EF4>(gk + s0, min(segL, n - s0), rec, sA, rq, sQ, wq, ent, lane, strip_lo, tile_x0, f.key_shift, wave, done, pass1);
+		}
+		sg.X[px_slot] = Cg + (double)(T * bgz);
+		return;
+	}
+	else
+	{
+		X = sg.X[px_slot];
+		const size_t o = (size_t)blockIdx.x * (size_t)FR_THREADS + (size_t)tid;
+		const float t0 = sg.snapT[o];
+		T = t0 < 0.f ? 1.0f : t0;
+		done = t0 < 0.f || !inside;
+		Cg = sg.snapC[o];
+	}
 
 	// ---- pass 2: the squares
-	T = 1.0f; Cg = 0.0;
-	done = !inside;
+	if constexpr (MODE == 0) { T = 1.0f; Cg = 0.0; done = !inside; }
 	const float dL2 = IMG ? 1.0f : f.dL * f.dL;
 	float* dst = f.out_H + (size_t)v * f.outH_stride;
 	auto pass2 = [&](uint32_t m, uint32_t my_id, unsigned long long emask) {
@@ -6626,7 +6670,7 @@ static void fr_launch_fisher_v3h(FrParams& p, FrFisherArgs f, float4* recq, FrSe
 }
 
 // the other out_H modes on records: 11 columns and / or an upstream-gradient image
-static void fr_launch_fisher_v3g(FrParams& p, FrFisherArgs f, int columns, bool img, hipStream_t s)
+static void fr_launch_fisher_v3g(FrParams& p, FrFisherArgs f, int columns, bool img, FrSegArgs sg, hipStream_t s)
 {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_prof_on)
@@ -6635,10 +6679,20 @@ static void fr_launch_fisher_v3g(FrParams& p, FrFisherArgs f, int columns, bool 
 		(void)hipEventRecord(ev0, s);
 	}
 	dim3 grid(p.T * p.V), block(FR_THREADS);
-	if (columns == 11 && img) hipLaunchKernelGGL((k_fisher_tile_v3g<11, true>), grid, block, 0, s, p, f);
-	else if (columns == 11) hipLaunchKernelGGL((k_fisher_tile_v3g<11, false>), grid, block, 0, s, p, f);
-	else if (img) hipLaunchKernelGGL((k_fisher_tile_v3g<4, true>), grid, block, 0, s, p, f);
-	else hipLaunchKernelGGL((k_fisher_tile_v3g<4, false>), grid, block, 0, s, p, f);
+	if (sg.snapT && p.T * p.V <= FR_SEG_TILES)
+	{
+		// few views (GaussianObjectSLAM.compute_Hessian of one pose, a handful of probes): the segmented passes, as for k_fisher_tile_v3h
+		(void)hipMemsetAsync(sg.list, 0, 4, s);
+		dim3 g2(FR_SEG_PER_TILE * p.T * p.V);
+		if (columns == 11 && img) { hipLaunchKernelGGL((k_fisher_tile_v3g<11, true, 1>), grid, block, 0, s, p, f, sg); hipLaunchKernelGGL((k_fisher_tile_v3g<11, true, 2>), g2, block, 0, s, p, f, sg); }
+		else if (columns == 11) { hipLaunchKernelGGL((k_fisher_tile_v3g<11, false, 1>), grid, block, 0, s, p, f, sg); hipLaunchKernelGGL((k_fisher_tile_v3g<11, false, 2>), g2, block, 0, s, p, f, sg); }
+		else if (img) { hipLaunchKernelGGL((k_fisher_tile_v3g<4, true, 1>), grid, block, 0, s, p, f, sg); hipLaunchKernelGGL((k_fisher_tile_v3g<4, true, 2>), g2, block, 0, s, p, f, sg); }
+		else { hipLaunchKernelGGL((k_fisher_tile_v3g<4, false, 1>), grid, block, 0, s, p, f, sg); hipLaunchKernelGGL((k_fisher_tile_v3g<4, false, 2>), g2, block, 0, s, p, f, sg); }
+	}
+	else if (columns == 11 && img) hipLaunchKernelGGL((k_fisher_tile_v3g<11, true, 0>), grid, block, 0, s, p, f, sg);
+	else if (columns == 11) hipLaunchKernelGGL((k_fisher_tile_v3g<11, false, 0>), grid, block, 0, s, p, f, sg);
+	else if (img) hipLaunchKernelGGL((k_fisher_tile_v3g<4, true, 0>), grid, block, 0, s, p, f, sg);
+	else hipLaunchKernelGGL((k_fisher_tile_v3g<4, false, 0>), grid, block, 0, s, p, f, sg);
 	if (g_prof_on)
 	{
 		(void)hipEventRecord(ev1, s);
@@ -6869,15 +6923,15 @@ extern "C" int fr_fisher_views(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 			tile_join.on = true;
 		}
 		if (v3) fr_launch_fisher_v3(pg, fg, pl.ra.recq, ts);
-		else if (v3h)
+		else if (v3h || v3g)
 		{
 			FrSegArgs sg;
 			sg.snapT = (float*)(ws + L.seg_T); sg.snapC = (double*)(ws + L.seg_C); sg.X = (double*)(ws + L.seg_X);
 			sg.list = (uint32_t*)(ws + L.seg_list);
 			if (pg.V * pg.T > FR_SEG_TILES) sg.snapT = nullptr;
-			fr_launch_fisher_v3h(pg, fg, pl.ra.recq, sg, ts);
+			if (v3h) fr_launch_fisher_v3h(pg, fg, pl.ra.recq, sg, ts);
+			else fr_launch_fisher_v3g(pg, fg, fc->columns, fc->dL_dpix_image != nullptr, sg, ts);
 		}
-		else if (v3g) fr_launch_fisher_v3g(pg, fg, fc->columns, fc->dL_dpix_image != nullptr, ts);
 		else if (fc->columns == 4) fr_launch_fisher<4>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
 		else fr_launch_fisher<11>(pg, fg, (float*)(ws + L.packed), (uint8_t*)(ws + L.fallback), ts);
 		if ((rc = fr_check_launch("k_fisher_tile"))) return rc;
