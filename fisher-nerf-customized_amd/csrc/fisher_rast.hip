@@ -941,8 +941,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 	__shared__ uint32_t s_n[FR_VC_MAX];          // visible pairs per view so far = the next slot of the view
 	__shared__ uint32_t s_ref[FR_VC_MAX];
 	__shared__ uint32_t s_ca[FR_VC_MAX * 4];     // phase A: survivors per (view, wave)
-	__shared__ uint32_t s_wk[FR_VC_MAX * 4];     // visible pairs per (view, wave) of the current batch
-	__shared__ uint32_t s_wtot[4];               // ... per wave
+	// Two barriers per batch, not four: the ballot counts are double-buffered (a fast wave may already count batch k + 1 while a slow
+	// one still ranks batch k), the views' running counts s_n move on behind the parking barrier (their readers are all in front of it,
+	// their next readers behind the next batch's first barrier), and park[] is rewritten only behind that next first barrier -- which no
+	// wave passes before every wave has finished phase C of batch k.
+	__shared__ uint32_t s_wk2[2][FR_VC_MAX * 4]; // visible pairs per (view, wave) of a batch
+	__shared__ uint32_t s_wtot2[2][4];           // ... per wave
+	uint32_t batch_no = 0;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int v0 = blockIdx.y * VC;
@@ -1140,6 +1145,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 			// in index order in it, and in every batch: a visible pair's rank among its view's visible pairs is the view's count of the
 			// earlier batches (s_n) + the same-view visible pairs of the lower waves + those of the lower lanes.  `pos` (its place among
 			// ALL visible pairs of the batch) only packs the batch for phase C.
+			uint32_t* s_wk = s_wk2[batch_no & 1u];
+			uint32_t* s_wtot = s_wtot2[batch_no & 1u];
+			batch_no++;
 			const unsigned long long mv = __builtin_amdgcn_ballot_w64(vis);
 			if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(mv);
 			uint32_t below = 0;                                     // same-view visible pairs in the lower lanes of this wave
@@ -1161,8 +1169,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				rank = s_n[vv] + below;
 				for (int w = 0; w < wave; w++) rank += s_wk[vv * 4 + w];
 			}
-			__syncthreads();                                        // every rank is taken: s_n and s_wk may change
-			if (tid < nv) s_n[tid] += (s_wk[tid * 4] + s_wk[tid * 4 + 1]) + (s_wk[tid * 4 + 2] + s_wk[tid * 4 + 3]);
 			if (vis)
 			{
 				// tile rectangle: the reference's radius rectangle (rasterizer_impl.cu:70-111) cut down to the tiles the conservative
@@ -1222,6 +1228,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				park[12 * FR_THREADS + pos] = rank | ((uint32_t)vv << 16);
 			}
 			__syncthreads();
+			if (tid < nv) s_n[tid] += (s_wk[tid * 4] + s_wk[tid * 4 + 1]) + (s_wk[tid * 4 + 2] + s_wk[tid * 4 + 3]);     // (every rank of this batch is taken)
 			// ---- phase C: the r-th visible pair of the batch
 			FR_ABL(if (p.ablate == 36) nvis = 0;)                   // 36: no phase C (no records, no list entries)
 			if ((uint32_t)tid < nvis)
@@ -1261,7 +1268,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				}
 				if constexpr (AF != 0) ra.slot_idx[(size_t)v * PV + slot] = p.order ? p.order[idx] : idx;    // (the out_H kernels go back to the caller's index)
 			}
-			__syncthreads();                                        // park[], s_wtot and s_wk are reused by the next batch
 		}
 		// what is left over moves to the front of the list
 		const uint32_t rem = pend - ndo;
@@ -1275,6 +1281,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 		}
 		pend = rem;
 	}
+	__syncthreads();                                 // every histogram add, every list entry and the last update of s_n are done and visible
 	if constexpr (DK)
 	{
 		uint32_t* cursor = park + 13 * FR_THREADS;
