@@ -3,31 +3,35 @@
 //
 // Pipeline (single view: V = 1; Fisher scorer: V candidate views in one launch):
 //   k_cov3d              once per call      scale/quaternion -> cov3D[P][6]            (forward.cu:118-152)
-//   k_pack_static        once per call      records modes: one 64 / 128-byte record per Gaussian (mean, cov3D, rgb, ..., H_inv)
+//   k_pack_static        once per call      records modes: one 64 / 128-byte record per Gaussian (mean, cov3D, rgb, ..., H_inv), {mean, trace},
+//                                           bounds of every 256 Gaussians; skipped under fr_fisher_cfg.reuse_static
 //   k_preprocess         (P/(256 G), V)     project, cull, conic, radius, tile rect, per-tile COUNT through an LDS histogram
-//   k_preprocess_views   (P/(256 G), V/VC)  the same for many views of one camera: near-plane + early frustum test, compaction,
-//                                           dense projection, compact visible lists, and (records modes) the scorer's
-//                                           per-(view, Gaussian) records                (forward.cu:155-256)
-//   k_scan_tiles         1 block            exclusive scan of the V*T tile counts -> segment offsets, device-side
-//                                           num_rendered / overflow flag (replaces cub::InclusiveSum + the blocking
-//                                           cudaMemcpy of rasterizer_impl.cu:277-282)
-//   k_scatter_keys/_vis  (P/(256 G), V)     emit (depth_bits<<32 | gaussian) into the tile's segment
+//   k_preprocess_views_c (P/(256 G), V/VC)  the scorer's front end for many views of one camera: near-plane + early frustum test, compaction,
+//                                           dense projection, compact visible lists, the scorer's per-(view, Gaussian) records written once,
+//                                           and (fixed key segments) the keys themselves   (forward.cu:155-256)
+//   k_tile_lists / k_scan_tiles             segment offsets (fixed / exclusive scan), device-side num_rendered / overflow flag (replaces
+//                                           cub::InclusiveSum + the blocking cudaMemcpy of rasterizer_impl.cu:277-282), list of long tiles
+//   k_scatter_keys/_vis  (P/(256 G), V)     packed lists: emit (depth_bits<<32 | gaussian) into the tile's segment
 //                                           (duplicateWithKeys, rasterizer_impl.cu:70-111)
-//   k_sort_tiles/_mid/_big                  per-tile bitonic network on the 64-bit keys, in registers (DPP / permlane exchanges
-//                                           between lanes, LDS only where waves' runs join): replaces the global
+//   k_sort_tiles, k_sort_part, k_sort_mid/_big   per-tile bitonic network on the 64-bit keys, in registers (DPP / permlane exchanges
+//                                           between lanes, LDS only where waves' runs join); long lists of fixed segments are first
+//                                           partitioned at sampled pivots into wave-sized parts: replaces the global
 //                                           cub::DeviceRadixSort (rasterizer_impl.cu:304-309).  Keys are unique, so the
 //                                           result equals the reference's stable (tile, depth) order with ties by index.
 //   k_render_forward_walk<3|6>  (T, V)      alpha compositing, median depth, wave-private strips, per-lane walk (forward.cu:261-393)
-//   k_backward_lin_tile<pair> + k_backward_finish   grad_power 1 (training): per-splat sums of the screen-space gradients,
-//                                           Jacobian chain once per Gaussian           (backward.cu:850-1140, 276-583)
+//   k_backward_lin_walk / k_backward_lin_tile<pair> + k_backward_finish   grad_power 1 (training): per-splat sums of the screen-space
+//                                           gradients, Jacobian chain once per Gaussian    (backward.cu:850-1140, 276-583)
+//   k_backward_sq_rows + k_backward_sq_walk grad_power 2 through the rasteriser API
 //   k_backward_tile      (T, 1)             generic fused backward, any grad_power, SH colours
-//   k_fisher_tile_v3     T*V                the scorer: sum(cur_H * H_inv) per view (gaussian.py:1548-1556, 1367) in ONE front-to-back
-//                                           pass over the records, no gradient tensor materialised
-//   k_fisher_tile_v3h    T*V                cur_H itself (4 columns): two front-to-back passes over the records
-//   k_fisher_tile_v2<4|11|25>  T*V          transmittance pass + backward(power=2) fused, wave-private: the other out_H modes
-//                                           (11 columns, gradient images, all 25 leaves of the rasteriser's power-2 backward)
+//   k_fisher_tile_v4     T*V                the scorer: sum(cur_H * H_inv) per view (gaussian.py:1548-1556, 1367) in ONE front-to-back
+//                                           pass over the records (rolling halves), no gradient tensor materialised
+//                                           (k_fisher_tile_v3: the chunk-synchronous form, for packed lists / dense records)
+//   k_fisher_tile_v3h / _v3g  T*V           cur_H itself (4 / 11 columns, gradient images): two front-to-back passes over the records;
+//                                           few views: <.., 1> pass 1 per tile + work list, <.., 2> pass 2 per list segment
+//   k_fisher_tile_v2<4|11>  T*V             transmittance pass + backward(power=2) fused, wave-private: H_inv AND out_H in one launch,
+//                                           11-column out_H beyond 4096 tiles
 //   k_fisher_tile        T*V                first-generation scan kernel: fallback for tiles beyond the LDS index of the above
-//   k_knn_*                                 simple-knn distCUDA2
+//   k_knn_*, fr_spatial_order               simple-knn distCUDA2; the Z-curve order of the Gaussians
 //
 // Wave64 mapping of a 16x16 tile: 256 threads = 4 waves, wave w owns the 16x4 pixel strip of rows 4w..4w+3, so a
 // small splat is seen by 1-2 waves and the others skip it with one ballot.
