@@ -5543,6 +5543,321 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_rows(FrParams p, flo
 	for (int k = 0; k < FR_SQ_ROWS / 4; k++) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
 }
 
+// One pixel's back-to-front state (backward.cu:938-1003) and the two halves of a pair's step: the test (is this candidate a
+// contributor of the pixel?) and the recurrences.  k_backward_sq_walk and k_backward_sq_state run the SAME code, so a pixel's
+// state at a segment boundary is bit for bit what the unsegmented walk would hold there.
+struct FrSqPix { float Tc, last_alpha, accum[3], lastc[3]; };
+__device__ __forceinline__ bool fr_sq_test(const float4& r0, const float4& r1, float pfx, float pfy, uint32_t ncontrib,
+                                           float& dx, float& dy, float& G, float& alpha)
+{
+	if (__float_as_uint(r1.w) >= ncontrib) return false;          // behind the pixel's last contributor (backward.cu:951-957)
+	const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
+	dx = r0.x - pfx; dy = r0.y - pfy;
+	const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+	if (power > 0.0f || power < r1.z) return false;
+	G = fr_expf_inrange(power);
+	alpha = fminf(0.99f, o * G);
+	return !(alpha < 1.0f / 255.0f);
+}
+// backward.cu:978-1003: returns dL_dalpha (before the background term)
+__device__ __forceinline__ float fr_sq_update(FrSqPix& st, float alpha, const float4& r2, const float (&g)[3])
+{
+	st.Tc = st.Tc / (1.f - alpha);
+	const float rc[3] = { r2.x, r2.y, r2.z };
+	float da = 0.f;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+	{
+		st.accum[c] = st.last_alpha * st.lastc[c] + (1.f - st.last_alpha) * st.accum[c];
+		st.lastc[c] = rc[c];
+		da += (rc[c] - st.accum[c]) * g[c];
+	}
+	da *= st.Tc;
+	st.last_alpha = alpha;
+	return da;
+}
+
+// Few tiles (one view of 256 x 256 is 256 workgroups on 256 CUs): the longest list sets the time of k_backward_sq_walk, and a splat
+// that covers a strip puts all 64 pixel-lanes on ONE of its LDS accumulators (ds_add_f64 on one address: 192 cycles; 25 of them per
+// step).  With a scratch buffer (fr_backward_ws) the backward of such an image is cut into CHUNKS of at most 64 candidates of one
+// strip, each an independent piece of work:
+//   k_backward_sq_slots    per tile: which segments of L keys (L = a third of the mean list length, >= 256, a multiple of 64) hold a
+//                          contributor of some pixel; segment k of tile t has slot floor(tile_off[t] / L) + t + k (unique, no prefix pass)
+//   k_backward_sq_chunks   per (tile, segment), a wave per strip: the candidates of the segment, back to front, 64 at a time; every
+//                          pixel-lane walks its candidates with the recurrences only and leaves the chunk's MAP of the pixel's state
+//                          {Tc, last alpha, last colour, accumulated colour} -> state: a factor for Tc, an affine map for the colour
+//                          behind, and the chunk's own last contributor (9 floats); plus the chunk's candidate list, every pixel's
+//                          candidate mask, and the chunk's entry on the work list (full chunks in front of the partial ones)
+//   k_backward_sq_prefix   per (tile, strip): composes the maps from the back of the list forwards and leaves, per chunk, every pixel's
+//                          state in front of it
+//   k_backward_sq_leaves   wave w of W takes entries w, w + W, ... of the work list (dealing the raw chunk slots left the slowest
+//                          wave 3.3 times the mean; a cursor cost 12 000 atomics on one address, a fifth of the kernel's time); the
+//                          candidates of a chunk go ONE AT A TIME through the whole wave: every lane tests its pixel (the arithmetic
+//                          of k_backward_sq_walk; lanes without the pair carry zeros), the 25 squares are summed over the wave in
+//                          registers (fr_reduce_scatter32) and lane 2 l adds leaf l's total to the Gaussian's gradient: one global
+//                          atomic instruction per (strip, candidate), no LDS accumulators.
+// Within a chunk the recurrences are the reference's, statement by statement; across chunks Tc is multiplied by the chunk's product
+// of 1 / (1 - alpha) instead of being divided step by step, and the colour behind goes through the composed affine maps (coefficients
+// in [0, 1]): a relative difference of a few 1e-7 per chunk in the state a chunk starts from.  Which pairs contribute does not depend
+// on the state (backward.cu:951-975), so the contributor sets are the single pass's.
+struct FrSqSegArgs {
+	uint32_t* slot_map;   // [n_slots] tile + 1, or 0
+	uint32_t* ctl;        // [0] full chunks listed, [1] last (partial) chunks listed
+	uint2* work;          // [2][n_chunks] the work list {chunk, tile << 2 | strip}: full chunks (64 candidates), then the last chunk of every (segment, strip)
+	uint2* pixmask;       // [n_chunks][64] per pixel-lane: which of the chunk's candidates may touch it (as 2 x u32)
+	uint2* ctodo;         // [n_chunks] which candidates touch any pixel of the strip
+	uint32_t* cnt;        // [n_slots][4] chunks of (slot, strip)
+	uint2* list;          // [n_chunks][64] {Gaussian, position in the tile's list}
+	float* summ;          // [n_chunks][9][64] the chunk's map; k_backward_sq_prefix overwrites rows 0-7 with the state in front of the chunk
+	uint32_t n_slots, n_chunks;
+};
+__host__ __device__ __forceinline__ uint32_t fr_sq_seg_length_of(uint32_t R, uint32_t T)
+{
+	const uint32_t d = 3u * T;
+	const uint32_t l = (((R + d - 1u) / d) + 63u) & ~63u;
+	return l < 256u ? 256u : l;
+}
+__device__ __forceinline__ uint32_t fr_sq_seg_length(const FrParams& p) { return fr_sq_seg_length_of((uint32_t)p.status[0], (uint32_t)p.T); }
+
+__global__ __launch_bounds__(FR_THREADS) void k_backward_sq_slots(FrParams p, FrBwdArgs b, FrSqSegArgs sg)
+{
+	__shared__ uint32_t s_nmax;
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	if (tid == 0) s_nmax = 0u;
+	__syncthreads();
+	uint32_t nmax = inside ? b.n_contrib[(size_t)p.W * pxy + pxx] : 0u;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o, 64); nmax = t > nmax ? t : nmax; }
+	if (lane == 0) atomicMax(&s_nmax, nmax);
+	__syncthreads();
+	const uint32_t n = p.tile_cnt[tile];
+	nmax = s_nmax < n ? s_nmax : n;
+	const uint32_t L = fr_sq_seg_length(p);
+	const uint32_t slot0 = p.tile_off[tile] / L + tile;
+	const uint32_t nseg = (nmax + L - 1u) / L;
+	for (uint32_t k = tid; k < nseg; k += FR_THREADS)
+		if (slot0 + k < sg.n_slots) sg.slot_map[slot0 + k] = tile + 1u;
+}
+
+// The map of one chunk on one pixel's state, built contributor by contributor (back to front)
+struct FrSqMap { float Pq, A, B[3], la, lc[3]; };      // la < 0: no contributor, the identity
+__device__ __forceinline__ void fr_sq_map_step(FrSqMap& mp, float alpha, const float4& r2)
+{
+	if (mp.la >= 0.f)
+	{
+		const float k = 1.f - mp.la;
+		mp.B[0] = mp.la * mp.lc[0] + k * mp.B[0]; mp.B[1] = mp.la * mp.lc[1] + k * mp.B[1]; mp.B[2] = mp.la * mp.lc[2] + k * mp.B[2];
+		mp.A = k * mp.A;
+	}
+	mp.Pq = mp.Pq / (1.f - alpha);
+	mp.la = alpha; mp.lc[0] = r2.x; mp.lc[1] = r2.y; mp.lc[2] = r2.z;
+}
+__device__ __forceinline__ void fr_sq_map_apply(FrSqPix& st, const FrSqMap& mp)
+{
+	if (!(mp.la >= 0.f)) return;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+	{
+		const float x = st.last_alpha * st.lastc[c] + (1.f - st.last_alpha) * st.accum[c];     // what the chunk's first contributor sees behind it
+		st.accum[c] = mp.B[c] + mp.A * x;                                                      // ... and its last one
+		st.lastc[c] = mp.lc[c];
+	}
+	st.Tc = st.Tc * mp.Pq;
+	st.last_alpha = mp.la;
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, FrBwdArgs b, FrSqSegArgs sg)
+{
+	__shared__ uint2 s_q[4][FR_QCAP];
+	__shared__ float4 s_ent[4][64][3];
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t slot = blockIdx.x;
+	const uint32_t t1 = sg.slot_map[slot];
+	if (t1 == 0u) return;                          // no (tile, segment) has this slot
+	const uint32_t tile = t1 - 1u;
+	const uint32_t L = fr_sq_seg_length(p), cmax = L >> 6;
+	const uint32_t seg_k = slot - (p.tile_off[tile] / L + tile);
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const float pfx = (float)pxx, pfy = (float)pxy;
+	const uint32_t n = p.tile_cnt[tile];
+	const uint64_t* gk = p.keys + p.tile_off[tile];
+	const float4* splat = (const float4*)p.splat;
+	uint2* wq = s_q[wave];
+	float4 (*ent)[3] = s_ent[wave];
+	const uint32_t ncontrib = inside ? b.n_contrib[(size_t)p.W * pxy + pxx] : 0u;
+	const uint32_t seg_lo = seg_k * L;
+	const uint32_t seg_hi = seg_lo + L < n ? seg_lo + L : n;
+	const float strip_lo = (float)(ty * FR_BLOCK_Y + 4u * (uint32_t)wave), strip_hi = strip_lo + 3.0f;
+	const float tile_x0 = (float)(tx * FR_BLOCK_X), tile_x1 = tile_x0 + 15.0f;
+	uint32_t nmax = ncontrib;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o, 64); nmax = t > nmax ? t : nmax; }
+	nmax = nmax < seg_hi ? nmax : seg_hi;
+
+	uint32_t qh = 0, qn = 0, nchunk = 0;
+	const int lowest = (int)seg_lo;
+	int base = nmax > seg_lo ? (int)((nmax - 1u) & ~63u) : lowest - 64;
+	while (true)
+	{
+		while (qn < 64u && base >= lowest)
+		{
+			const uint32_t pos = (uint32_t)base + (uint32_t)lane;
+			bool ov = false;
+			uint32_t id = 0;
+			if (pos < nmax)
+			{
+				id = (uint32_t)gk[pos];
+				const float4 q0 = splat[2 * (size_t)id], q1 = splat[2 * (size_t)id + 1];
+				const uint32_t eb = __float_as_uint(q1.w);
+				const float hx = __half2float(__ushort_as_half((unsigned short)(eb & 0xffffu)));
+				const float hy = __half2float(__ushort_as_half((unsigned short)(eb >> 16)));
+				ov = hx >= 0.f && (q0.y + hy >= strip_lo) && (q0.y - hy <= strip_hi) && (q0.x + hx >= tile_x0) && (q0.x - hx <= tile_x1);
+			}
+			const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+			if (ov) wq[(qh + qn + (uint32_t)__popcll(lane < 63 ? (om >> (lane + 1)) : 0ull)) & (FR_QCAP - 1)] = make_uint2(id, pos);
+			qn += (uint32_t)__popcll(om);
+			base -= 64;
+		}
+		if (qn == 0) break;
+		const uint32_t m = qn < 64u ? qn : 64u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const size_t cid = ((size_t)slot * 4 + (size_t)wave) * cmax + nchunk;
+		const bool room = nchunk < cmax && cid < sg.n_chunks;          // (always: a segment of L keys has at most L / 64 chunks per strip)
+		unsigned long long emask = 0ull;
+		uint2 qe = make_uint2(0u, 0u);
+		if ((uint32_t)lane < m)
+		{
+			qe = wq[(qh + lane) & (FR_QCAP - 1)];
+			const float4 q0 = splat[2 * (size_t)qe.x], q1 = splat[2 * (size_t)qe.x + 1];
+			ent[lane][0] = q0;
+			ent[lane][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(qe.y));
+			ent[lane][2] = make_float4(b.colors[3 * (size_t)qe.x], b.colors[3 * (size_t)qe.x + 1], b.colors[3 * (size_t)qe.x + 2], 0.f);
+			const float4 a = make_float4(q0.x, q0.y, q1.w, __builtin_amdgcn_logf(q1.y));
+			const float4 b4 = make_float4(-0.5f * q0.z, -q0.w, -0.5f * q1.x, 0.f);
+			emask = fr_footprint_mask<16, 4>(a, b4, strip_lo, tile_x0);
+		}
+		qh = (qh + m) & (FR_QCAP - 1); qn -= m;
+		const unsigned long long todo = __builtin_amdgcn_ballot_w64(emask != 0ull);
+		unsigned long long mask = fr_wave_transpose64(emask, lane);
+		if (!inside) mask = 0ull;
+		if (room)
+		{
+			sg.list[cid * 64 + lane] = qe;
+			sg.pixmask[cid * 64 + lane] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
+			if (lane == 0) sg.ctodo[cid] = make_uint2((uint32_t)todo, (uint32_t)(todo >> 32));
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		FrSqMap mp;
+		mp.Pq = 1.f; mp.A = 1.f; mp.la = -1.f;
+#pragma unroll
+		for (int c = 0; c < 3; c++) { mp.B[c] = 0.f; mp.lc[c] = 0.f; }
+		while (mask != 0ull)
+		{
+			const int j = __ffsll((long long)mask) - 1;
+			mask &= mask - 1ull;
+			const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
+			float dx, dy, G, alpha;
+			if (!fr_sq_test(r0, r1, pfx, pfy, ncontrib, dx, dy, G, alpha)) continue;
+			fr_sq_map_step(mp, alpha, r2);
+		}
+		if (room)
+		{
+			float* sm = sg.summ + cid * (9 * 64) + lane;
+			sm[0 * 64] = mp.Pq; sm[1 * 64] = mp.A; sm[2 * 64] = mp.B[0]; sm[3 * 64] = mp.B[1]; sm[4 * 64] = mp.B[2];
+			sm[5 * 64] = mp.la; sm[6 * 64] = mp.lc[0]; sm[7 * 64] = mp.lc[1]; sm[8 * 64] = mp.lc[2];
+			nchunk++;
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (lane == 0)
+	{
+		sg.cnt[(size_t)slot * 4 + wave] = nchunk;
+		// the work list of k_backward_sq_leaves: all but the last chunk of a (segment, strip) hold 64 candidates, and those go first
+		if (nchunk > 0u)
+		{
+			const uint32_t cid0 = (slot * 4u + (uint32_t)wave) * cmax, where = tile << 2 | (uint32_t)wave;
+			// one 64-bit add moves both counters: ctl[0] (low word) += the full chunks, ctl[1] (high word) += 1
+			const unsigned long long old = atomicAdd((unsigned long long*)sg.ctl, (1ull << 32) | (unsigned long long)(nchunk - 1u));
+			const uint32_t wh = (uint32_t)old, wl = (uint32_t)(old >> 32);
+			if (wl < sg.n_chunks) sg.work[(size_t)sg.n_chunks + wl] = make_uint2(cid0 + nchunk - 1u, where);
+			for (uint32_t c = 0; c + 1u < nchunk; c++) if (wh + c < sg.n_chunks) sg.work[wh + c] = make_uint2(cid0 + c, where);
+		}
+	}
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_backward_sq_prefix(FrParams p, FrBwdArgs b, FrSqSegArgs sg)
+{
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
+	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+	const uint32_t n = p.tile_cnt[tile];
+	const uint32_t L = fr_sq_seg_length(p), cmax = L >> 6;
+	const uint32_t slot0 = p.tile_off[tile] / L + tile;
+	FrSqPix st;
+	st.Tc = inside ? b.final_T[(size_t)p.W * pxy + pxx] : 0.f; st.last_alpha = 0.f;
+#pragma unroll
+	for (int c = 0; c < 3; c++) { st.accum[c] = 0.f; st.lastc[c] = 0.f; }
+	// segments from the back of the list, 64 at a time: lane i looks up segment kb - i, the wave then goes through them in order
+	for (int kb = (int)((n + L - 1u) / L) - 1; kb >= 0; kb -= 64)
+	{
+		const int my_k = kb - lane;
+		uint32_t my_nc = 0u;
+		if (my_k >= 0)
+		{
+			const uint32_t slot = slot0 + (uint32_t)my_k;
+			if (slot < sg.n_slots && sg.slot_map[slot] != 0u) my_nc = sg.cnt[(size_t)slot * 4 + wave];     // 0: behind every pixel's last contributor
+		}
+		const int nk = kb + 1 < 64 ? kb + 1 : 64;
+		for (int i = 0; i < nk; i++)
+		{
+			const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)my_nc, i);
+			if (nc == 0u) continue;
+			const size_t cid0 = ((size_t)(slot0 + (uint32_t)(kb - i)) * 4 + (size_t)wave) * cmax;
+			for (uint32_t c0 = 0; c0 < nc; c0 += 4u)
+			{
+				// the maps of up to four chunks first (independent loads), then the chain
+				FrSqMap mp[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					mp[u].la = -1.f; mp[u].Pq = 1.f; mp[u].A = 1.f;
+					mp[u].B[0] = mp[u].B[1] = mp[u].B[2] = 0.f; mp[u].lc[0] = mp[u].lc[1] = mp[u].lc[2] = 0.f;
+					if (c0 + (uint32_t)u < nc)
+					{
+						const float* sm = sg.summ + (cid0 + c0 + u) * (9 * 64) + lane;
+						mp[u].Pq = sm[0 * 64]; mp[u].A = sm[1 * 64]; mp[u].B[0] = sm[2 * 64]; mp[u].B[1] = sm[3 * 64]; mp[u].B[2] = sm[4 * 64];
+						mp[u].la = sm[5 * 64]; mp[u].lc[0] = sm[6 * 64]; mp[u].lc[1] = sm[7 * 64]; mp[u].lc[2] = sm[8 * 64];
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					if (c0 + (uint32_t)u < nc)
+					{
+						float* sm = sg.summ + (cid0 + c0 + u) * (9 * 64) + lane;
+						sm[0 * 64] = st.Tc; sm[1 * 64] = st.last_alpha; sm[2 * 64] = st.accum[0]; sm[3 * 64] = st.accum[1]; sm[4 * 64] = st.accum[2];
+						sm[5 * 64] = st.lastc[0]; sm[6 * 64] = st.lastc[1]; sm[7 * 64] = st.lastc[2];
+						fr_sq_map_apply(st, mp[u]);
+					}
+			}
+		}
+	}
+}
+
 __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_walk(FrParams p, FrBwdArgs b, const float* __restrict__ rows)
 {
 	constexpr int EF4 = 3 + FR_SQ_ROWS / 4;      // 17 float4 per parked candidate (odd: sixteen consecutive records cover all LDS banks)
@@ -5567,8 +5882,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_walk(FrParams p, FrB
 	const size_t pix = (size_t)p.W * pxy + pxx;
 	const float T_final = inside ? b.final_T[pix] : 0.f;
 	const uint32_t ncontrib = inside ? b.n_contrib[pix] : 0u;
-	float Tc = T_final, last_alpha = 0.f;
-	float accum[3] = { 0.f, 0.f, 0.f }, lastc[3] = { 0.f, 0.f, 0.f }, g[3] = { 0.f, 0.f, 0.f };
+	FrSqPix st;
+	st.Tc = T_final; st.last_alpha = 0.f;
+#pragma unroll
+	for (int c = 0; c < 3; c++) { st.accum[c] = 0.f; st.lastc[c] = 0.f; }
+	float g[3] = { 0.f, 0.f, 0.f };
 	if (inside) { g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix]; }
 	const float bg_dot = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
 	const float hw = (float)(0.5 * p.W), hh = (float)(0.5 * p.H);
@@ -5635,28 +5953,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_walk(FrParams p, FrB
 			const int j = __ffsll((long long)mask) - 1;
 			mask &= mask - 1ull;
 			const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
-			if (__float_as_uint(r1.w) >= ncontrib) continue;          // behind the pixel's last contributor (backward.cu:951-957)
+			float dx, dy, G, alpha;
+			if (!fr_sq_test(r0, r1, pfx, pfy, ncontrib, dx, dy, G, alpha)) continue;
 			const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
-			const float dx = r0.x - pfx, dy = r0.y - pfy;
-			const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-			if (power > 0.0f || power < r1.z) continue;
-			const float G = fr_expf_inrange(power);
-			const float alpha = fminf(0.99f, o * G);
-			if (alpha < 1.0f / 255.0f) continue;
 			// backward.cu:978-1038
-			Tc = Tc / (1.f - alpha);
-			const float wcol = alpha * Tc;
-			const float rc[3] = { r2.x, r2.y, r2.z };
-			float da = 0.f;
-#pragma unroll
-			for (int c = 0; c < 3; c++)
-			{
-				accum[c] = last_alpha * lastc[c] + (1.f - last_alpha) * accum[c];
-				lastc[c] = rc[c];
-				da += (rc[c] - accum[c]) * g[c];
-			}
-			da *= Tc;
-			last_alpha = alpha;
+			float da = fr_sq_update(st, alpha, r2, g);
+			const float wcol = alpha * st.Tc;
 			if (bg_dot != 0.f) da += (-T_final / (1.f - alpha)) * bg_dot;
 			const float w = (o * da) * G;                                    // dL_dG * G
 			const float ux = -(cx * dx + cy * dy), uy = -(cy * dx + cz * dy);   // u = -conic d
@@ -5721,6 +6023,200 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_walk(FrParams p, FrB
 			for (int c = 0; c < 4; c++) if ((a = (float)s_acc[wave][21 + c][lane]) != 0.f) atomicAdd(b.dL_drot + 4 * id + c, a);
 		}
 		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+// Sum of 32 per-lane values over the 64 lanes, all 32 at once: a butterfly in which a lane hands half of what it still holds to its
+// partner and adds the partner's other half to its own (16 v_permlane32_swap, 8 v_permlane16_swap, then 4 + 2 + 1 values over DPP):
+// 72 instructions instead of 32 x 6.  Lane l returns the total of v[l >> 1].  All 64 lanes must be executing.
+__device__ __forceinline__ float fr_reduce_scatter32(float (&v)[32], int lane)
+{
+	float s[16], t[8], r[4], q[2];
+#pragma unroll
+	for (int k = 0; k < 16; k++)
+	{
+		const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 16]), false, false);
+		s[k] = __uint_as_float(x[0]) + __uint_as_float(x[1]);       // lanes < 32: v[k] of both halves; lanes >= 32: v[k + 16]
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+	{
+		const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 8]), false, false);
+		t[k] = __uint_as_float(x[0]) + __uint_as_float(x[1]);       // even rows: s[k]; odd rows: s[k + 8]
+	}
+	const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+	{
+		const float keep = b3 ? t[k + 4] : t[k], send = b3 ? t[k] : t[k + 4];
+		r[k] = keep + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send), 0x128, 0xf, 0xf, false));     // row_ror:8
+	}
+#pragma unroll
+	for (int k = 0; k < 2; k++)
+	{
+		const float keep = b2 ? r[k + 2] : r[k], send = b2 ? r[k] : r[k + 2];
+		const int o = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)__float_as_uint(send), 0x1B, 0xf, 0xf, false), 0x141, 0xf, 0xf, false);   // lane ^ 4
+		q[k] = keep + __uint_as_float((uint32_t)o);
+	}
+	const float keep = b1 ? q[1] : q[0], send = b1 ? q[0] : q[1];
+	const float h = keep + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+	return h + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(h), 0xB1, 0xf, 0xf, false));                 // quad_perm [1,0,3,2]
+}
+
+__global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p, FrBwdArgs b, const float* __restrict__ rows, FrSqSegArgs sg)
+{
+	constexpr int NR4 = FR_SQ_ROWS / 4;
+	__shared__ float4 s_ent[4][32][3];            // half a chunk at a time: 34 KiB per workgroup, four workgroups per CU
+	__shared__ float4 s_rows[4][NR4][32];         // the leaf rows, [float4 of the row block][candidate]: written by LDS-direct loads
+	if (p.status[1]) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const float4* splat = (const float4*)p.splat;
+	float4 (*ent)[3] = s_ent[wave];
+	float4 (*rws)[32] = s_rows[wave];
+	const size_t HW = (size_t)p.H * p.W;
+	const float hw = (float)(0.5 * p.W), hh = (float)(0.5 * p.H);
+
+	// where this lane's total goes: lane 2 l holds leaf l (fr_reduce_scatter32); leaves in FR_SQ_NL order
+	float* dst = nullptr;
+	uint32_t dstride = 0;
+	{
+		const int l = lane >> 1;
+		if (!(lane & 1) && l < FR_SQ_NL)
+		{
+			if (l < 2) { dst = b.dL_dmean2D + l; dstride = 3; }
+			else if (l < 5) { dst = b.dL_dconic + (l == 4 ? 3 : l - 2); dstride = 4; }
+			else if (l < 8) { dst = b.dL_dcolors + (l - 5); dstride = 3; }
+			else if (l < 9) { dst = b.dL_dopacity; dstride = 1; }
+			else if (l < 12) { dst = b.dL_dmean3D + (l - 9); dstride = 3; }
+			else if (l < 18) { dst = b.dL_dcov3D + (l - 12); dstride = 6; }
+			else if (l < 21) { dst = b.dL_dscale + (l - 18); dstride = 3; }
+			else { dst = b.dL_drot + (l - 21); dstride = 4; }
+		}
+	}
+
+	const uint32_t n_full = sg.ctl[0] < sg.n_chunks ? sg.ctl[0] : sg.n_chunks, n_last = sg.ctl[1] < sg.n_chunks ? sg.ctl[1] : sg.n_chunks;
+	const uint32_t n_work = n_full + n_last;
+	// wave w of W takes items w, w + W, ... of the list (full chunks first): every wave gets its share of the full chunks, and no
+	// cursor (12 000 atomics on one address were a fifth of the kernel's time)
+	const uint32_t W_all = gridDim.x * 4u;
+	for (uint32_t wi = blockIdx.x * 4u + (uint32_t)wave; wi < n_work; wi += W_all)
+	{
+		{
+			const uint2 we = wi < n_full ? sg.work[wi] : sg.work[(size_t)sg.n_chunks + (wi - n_full)];
+			const size_t cid = we.x;
+			const uint32_t tile = we.y >> 2, strip = we.y & 3u;
+			const uint32_t tx = tile % p.gx, ty = tile / p.gx;
+			const uint32_t pxx = tx * FR_BLOCK_X + ((uint32_t)lane & 15u), pxy = ty * FR_BLOCK_Y + 4u * strip + ((uint32_t)lane >> 4);
+			const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
+			const float pfx = (float)pxx, pfy = (float)pxy;
+			const size_t pix = (size_t)p.W * pxy + pxx;
+			const float T_final = inside ? b.final_T[pix] : 0.f;
+			const uint32_t ncontrib = inside ? b.n_contrib[pix] : 0u;
+			float g[3] = { 0.f, 0.f, 0.f };
+			if (inside) { g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix]; }
+			const float bg_dot = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
+			FrSqPix st;
+			{
+				const float* sm = sg.summ + cid * (9 * 64) + lane;          // the state in front of the chunk (k_backward_sq_prefix)
+				st.Tc = sm[0 * 64]; st.last_alpha = sm[1 * 64]; st.accum[0] = sm[2 * 64]; st.accum[1] = sm[3 * 64]; st.accum[2] = sm[4 * 64];
+				st.lastc[0] = sm[5 * 64]; st.lastc[1] = sm[6 * 64]; st.lastc[2] = sm[7 * 64];
+			}
+			uint32_t my_id, my_pos;
+			{ const uint2 qe = sg.list[cid * 64 + lane]; my_id = qe.x; my_pos = qe.y; }          // (lanes beyond the chunk's candidates: {0, 0}, parked but never read)
+			const float4 q0 = splat[2 * (size_t)my_id], q1 = splat[2 * (size_t)my_id + 1];      // {x, y, conx, cony} {conz, opacity, depth, ext}
+			unsigned long long todo_all, mask;
+			{ const uint2 t = sg.ctodo[cid]; todo_all = (unsigned long long)t.y << 32 | t.x; }
+			{ const uint2 t = sg.pixmask[cid * 64 + lane]; mask = (unsigned long long)t.y << 32 | t.x; }
+			// back to front: the chunk holds its candidates in descending list position, lane 0 first; 32 of them are parked at a time
+			for (int h = 0; h < 2; h++)
+			{
+				unsigned long long todo = h ? (todo_all >> 32) << 32 : todo_all & 0xffffffffull;
+				if (todo == 0ull) continue;
+				__builtin_amdgcn_wave_barrier();                                // the reads of what ent held before are done
+				if ((lane >> 5) == h)
+				{
+					const int e = lane & 31;
+					ent[e][0] = q0;
+					ent[e][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(my_pos));
+					ent[e][2] = make_float4(b.colors[3 * (size_t)my_id], b.colors[3 * (size_t)my_id + 1], b.colors[3 * (size_t)my_id + 2], 0.f);
+				}
+				{
+					// the 224 bytes of leaf rows of the 32 candidates, global memory -> LDS with no register in between (through registers the
+					// compiler waits for each of the fourteen loads in turn): one instruction moves float4 2 kk of the 32 candidates on lanes
+					// 0-31 and float4 2 kk + 1 on lanes 32-63 -- the lane-linear image the LDS-direct load writes is exactly rws[2 kk .. 2 kk + 1][.]
+					const uint32_t cand_id = (uint32_t)__shfl((int)my_id, (lane & 31) + 32 * h, 64);     // (a candidate beyond m: Gaussian 0's rows, never read)
+					const float4* rsrc = (const float4*)(rows + (size_t)cand_id * FR_SQ_ROWS) + (lane >> 5);
+#pragma unroll
+					for (int kk = 0; kk < NR4 / 2; kk++) __builtin_amdgcn_global_load_lds(rsrc + 2 * kk, &rws[2 * kk][0], 16, 0, 0);
+					__builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				while (todo != 0ull)
+				{
+					const int jj = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+					todo &= todo - 1ull;
+					const int j = jj & 31;
+					const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
+					float dx = 0.f, dy = 0.f, G = 0.f, alpha = 0.f;
+					const bool ok = ((mask >> jj) & 1ull) != 0ull && fr_sq_test(r0, r1, pfx, pfy, ncontrib, dx, dy, G, alpha);
+					if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+					const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
+					float w = 0.f, wcol = 0.f;
+					if (ok)
+					{
+						// backward.cu:978-1038
+						float da = fr_sq_update(st, alpha, r2, g);
+						wcol = alpha * st.Tc;
+						if (bg_dot != 0.f) da += (-T_final / (1.f - alpha)) * bg_dot;
+						w = (o * da) * G;                                              // dL_dG * G
+					}
+					// from here on every lane executes: a lane without the pair carries w = wcol = 0, so all its squares are 0
+					const float ux = -(cx * dx + cy * dy), uy = -(cy * dx + cz * dy);   // u = -conic d
+					const float uxx = ux * ux, uxy = ux * uy, uyy = uy * uy;
+					float v[32];
+					{
+						const float l0 = w * ux * hw, l1 = w * uy * hh;                                   // dL_dmean2D (backward.cu:1021-1024)
+						const float hq = -0.5f * w;
+						const float l2 = hq * dx * dx, l3 = hq * dx * dy, l4 = hq * dy * dy;               // dL_dconic x, y, w (1026-1029)
+						v[0] = l0 * l0; v[1] = l1 * l1; v[2] = l2 * l2; v[3] = l3 * l3; v[4] = l4 * l4;
+					}
+#pragma unroll
+					for (int c = 0; c < 3; c++) { const float l = wcol * g[c]; v[5 + c] = l * l; }         // dL_dcolors
+					{
+						const float4 rz = rws[13][j];                                                     // rows[52..55]: {.., .., 1 / opacity^2, pad}
+						v[8] = w * w * rz.z;                                                               // dL_dopacity = G dL_dalpha = w / opacity
+					}
+					// the 16 rows: mean 3 x 5, then cov3D 6 x 3 and scale / rotation 7 x 3 over (ux^2, ux uy, uy^2), applied to w gamma
+					float rf[FR_SQ_ROWS];
+#pragma unroll
+					for (int k = 0; k < NR4; k++)
+					{
+						const float4 t = rws[k][j];
+						rf[4 * k] = t.x; rf[4 * k + 1] = t.y; rf[4 * k + 2] = t.z; rf[4 * k + 3] = t.w;
+					}
+					const float g0 = w * ux, g1 = w * uy, g2 = w * uxx, g3 = w * uxy, g4 = w * uyy;
+#pragma unroll
+					for (int r = 0; r < 3; r++)
+					{
+						const float l = rf[r * 5] * g0 + rf[r * 5 + 1] * g1 + rf[r * 5 + 2] * g2 + rf[r * 5 + 3] * g3 + rf[r * 5 + 4] * g4;
+						v[9 + r] = l * l;
+					}
+#pragma unroll
+					for (int r = 0; r < 13; r++)
+					{
+						const float l = rf[15 + r * 3] * g2 + rf[15 + r * 3 + 1] * g3 + rf[15 + r * 3 + 2] * g4;
+						v[12 + r] = l * l;
+					}
+#pragma unroll
+					for (int k = FR_SQ_NL; k < 32; k++) v[k] = 0.f;
+					const float tot = fr_reduce_scatter32(v, lane);
+					const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, jj);
+					if (dst != nullptr && tot != 0.f) atomicAdd(dst + (size_t)id * dstride, tot);
+				}
+			}
+		}
 	}
 }
 
@@ -6000,7 +6496,9 @@ static void fr_fill_params(FrParams& p, const fr_raster_cfg* cfg, const fr_gauss
 // Launches cov3d, preprocess, scan, scatter, sort for V views.  p must carry the carved buffers.
 // One launch instead of a dozen memsets: zero-fills up to FR_ZERO_MAX device buffers (all sizes multiples of 4 bytes).
 #define FR_ZERO_MAX 12
-struct FrZeroList { uint32_t* ptr[FR_ZERO_MAX]; unsigned long long end[FR_ZERO_MAX]; int n; };   // end[i]: prefix sum of dwords
+// Up to FR_ZERO_MAX buffers cleared by one launch, in units of 16 bytes (a buffer's last unit may be shorter): end[i] = prefix sum
+// of the units, dwords[i] = the buffer's length.  A buffer whose address is not 16-byte aligned is cleared dword by dword.
+struct FrZeroList { uint32_t* ptr[FR_ZERO_MAX]; unsigned long long end[FR_ZERO_MAX]; unsigned long long dwords[FR_ZERO_MAX]; int n; };
 __global__ __launch_bounds__(FR_THREADS) void k_zero_many(FrZeroList z)
 {
 	const unsigned long long total = z.end[z.n - 1];
@@ -6008,13 +6506,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_zero_many(FrZeroList z)
 	{
 		int b = 0;
 		while (i >= z.end[b]) b++;
-		z.ptr[b][i - (b ? z.end[b - 1] : 0ull)] = 0u;
+		const unsigned long long u = i - (b ? z.end[b - 1] : 0ull);
+		uint32_t* q = z.ptr[b] + 4 * u;
+		if (4 * u + 4 <= z.dwords[b] && ((uintptr_t)q & 15u) == 0) *(uint4*)q = make_uint4(0u, 0u, 0u, 0u);
+		else
+			for (unsigned long long k = 4 * u; k < 4 * u + 4 && k < z.dwords[b]; k++) z.ptr[b][k] = 0u;
 	}
 }
 struct FrZeroer {
 	FrZeroList z; unsigned long long run = 0;
 	FrZeroer() { z.n = 0; }
-	void add(void* p, size_t bytes) { if (!p || bytes == 0) return; z.ptr[z.n] = (uint32_t*)p; run += bytes / 4; z.end[z.n] = run; z.n++; }
+	void add(void* p, size_t bytes) { if (!p || bytes == 0) return; z.ptr[z.n] = (uint32_t*)p; z.dwords[z.n] = bytes / 4; run += (bytes / 4 + 3) / 4; z.end[z.n] = run; z.n++; }
 	void launch(hipStream_t s)
 	{
 		if (z.n == 0) return;
@@ -6306,12 +6808,54 @@ extern "C" int fr_forward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 	return fr_forward_impl(cfg, g, features, geom_ws, binning_ws, binning_capacity, image_ws, out_color, out_features, out_depth, radii, status, stream);
 }
 
+// Scratch of the chunked power-2 backward (k_backward_sq_slots / _chunks / _prefix / _leaves).  With R tile instances and T tiles:
+// L = max(256, a third of the mean list length rounded up to 64) keys per segment, at most R / L + T + 1 segment slots, L / 64 chunk
+// slots per (segment, strip); per chunk slot its candidate list (512 B) and nine floats per pixel-lane (2304 B).
+#define FR_SQ_SEG_MAX_TILES 1024     // beyond (a 512 x 512 image) the tiles alone fill the CUs
+struct FrSqScratch { size_t slot_map, ctl, cnt, work, ctodo, list, pixmask, summ, bytes; uint32_t n_slots, n_chunks; };
+static FrSqScratch fr_sq_scratch(int64_t T, int64_t R)
+{
+	FrSqScratch q;
+	const uint32_t L = fr_sq_seg_length_of((uint32_t)(R > 0 ? R : 1), (uint32_t)T);
+	q.n_slots = (uint32_t)((R > 0 ? R : 1) / L + T + 2);
+	q.n_chunks = q.n_slots * 4u * (L / 64u);
+	size_t o = 0;
+	q.slot_map = o; o = fr_align(o + (size_t)q.n_slots * 4);
+	q.ctl = o; o = fr_align(o + 64);                      // (zeroed together with the slot map: fr_backward_ws)
+	q.cnt = o; o = fr_align(o + (size_t)q.n_slots * 16);
+	q.work = o; o = fr_align(o + (size_t)q.n_chunks * 2 * sizeof(uint2));
+	q.ctodo = o; o = fr_align(o + (size_t)q.n_chunks * sizeof(uint2));
+	q.pixmask = o; o = fr_align(o + (size_t)q.n_chunks * 64 * sizeof(uint2));
+	q.list = o; o = fr_align(o + (size_t)q.n_chunks * 64 * sizeof(uint2));
+	q.summ = o; o = fr_align(o + (size_t)q.n_chunks * 9 * 64 * sizeof(float));
+	q.bytes = o;
+	return q;
+}
+extern "C" size_t fr_backward_scratch_bytes(int32_t P, int32_t W, int32_t H, int32_t power, int64_t num_rendered)
+{
+	if (P <= 0 || W <= 0 || H <= 0 || power != 2 || num_rendered <= 0 || num_rendered > 0x7fffffffll) return 0;
+	const int64_t T = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
+	if (T > FR_SQ_SEG_MAX_TILES) return 0;
+	return fr_sq_scratch(T, num_rendered).bytes;
+}
+
 extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
                            const void* geom_ws, const void* binning_ws, const void* image_ws,
                            const float* dL_dout_color, int32_t power,
                            float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
                            fr_stream_t stream)
+{
+	return fr_backward_ws(cfg, g, radii, geom_ws, binning_ws, image_ws, dL_dout_color, power, dL_dmeans2D, dL_dcolors, dL_dopacity,
+	                      dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dconic, 0, nullptr, 0, stream);
+}
+
+extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                              const void* geom_ws, const void* binning_ws, const void* image_ws,
+                              const float* dL_dout_color, int32_t power,
+                              float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
+                              float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
+                              int64_t num_rendered, void* scratch, size_t scratch_bytes, fr_stream_t stream)
 {
 	int rc = fr_validate(cfg, g, "fr_backward", false);
 	if (rc) return rc;
@@ -6322,12 +6866,19 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 	    !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_dconic)
 		return fr_fail(FR_EINVAL, "fr_backward: null pointer");
 	if (g->shs && !dL_dsh) return fr_fail(FR_EINVAL, "fr_backward: dL_dsh is null although SHs were given");
+	const bool sq_rows_path = power == 2 && g->scales && !g->shs && g->colors_precomp && !g->cov3D_precomp && fr_debug_mode() != 21;
+	const int64_t T_img = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
+	// few tiles and a scratch buffer: the chunked form (FR_DEBUG_MODE=33 in the rig: one workgroup per tile whatever the scratch)
+	const size_t scratch_need = sq_rows_path ? fr_backward_scratch_bytes(P, W, H, 2, num_rendered) : 0;
+	const bool segmented = sq_rows_path && scratch && scratch_need > 0 && scratch_bytes >= scratch_need FR_AB_ONLY(&& fr_debug_mode() != 33);
+	const FrSqScratch sq = fr_sq_scratch(T_img, segmented ? num_rendered : 1);
 	{
 		FrZeroer z;
 		z.add(dL_dmeans2D, (size_t)P * 3 * 4); z.add(dL_dcolors, (size_t)P * 3 * 4); z.add(dL_dopacity, (size_t)P * 4);
 		z.add(dL_dmeans3D, (size_t)P * 3 * 4); z.add(dL_dcov3D, (size_t)P * 6 * 4); z.add(dL_dscales, (size_t)P * 3 * 4);
 		z.add(dL_drotations, (size_t)P * 4 * 4); z.add(dL_dconic, (size_t)P * 4 * 4);
 		if (dL_dsh && cfg->sh_coeffs > 0) z.add(dL_dsh, (size_t)P * cfg->sh_coeffs * 3 * 4);
+		if (segmented) z.add((char*)scratch + sq.slot_map, sq.cnt - sq.slot_map);      // the slot map and the work list's counters
 		z.launch(s);
 	}
 
@@ -6384,7 +6935,7 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		else hipLaunchKernelGGL((k_backward_finish<false, false>), gp, block, 0, s, p, b, dL_dsh);
 		return fr_check_launch("k_backward_finish");
 	}
-	if (power == 2 && sr && !sh && g->colors_precomp && !g->cov3D_precomp && fr_debug_mode() != 21)
+	if (sq_rows_path)
 	{
 		// The diagonal Fisher proxy as the reference's own loop asks for it (gaussian.py:1536-1556: one view, autograd, power 2):
 		// the leaf rows once per visible Gaussian (k_backward_sq_rows), then the walking tile kernel (k_backward_sq_walk).
@@ -6392,6 +6943,26 @@ extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, cons
 		float* rows = (float*)((char*)geom_ws + L.packed);           // [P][56] floats of the geometry buffer's 256-byte-per-Gaussian region
 		hipLaunchKernelGGL(k_backward_sq_rows, dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, rows);
 		if ((rc = fr_check_launch("k_backward_sq_rows"))) return rc;
+		if (segmented)
+		{
+			// (the kernels size their segments from status[0]; num_rendered must be that number: the layout above depends on it)
+			FrSqSegArgs sg;
+			char* sc = (char*)scratch;
+			sg.slot_map = (uint32_t*)(sc + sq.slot_map); sg.ctl = (uint32_t*)(sc + sq.ctl); sg.cnt = (uint32_t*)(sc + sq.cnt);
+			sg.work = (uint2*)(sc + sq.work); sg.ctodo = (uint2*)(sc + sq.ctodo); sg.pixmask = (uint2*)(sc + sq.pixmask);
+			sg.list = (uint2*)(sc + sq.list); sg.summ = (float*)(sc + sq.summ);
+			sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks;
+			hipLaunchKernelGGL(k_backward_sq_slots, dim3(p.T), block, 0, s, p, b, sg);
+			if ((rc = fr_check_launch("k_backward_sq_slots"))) return rc;
+			hipLaunchKernelGGL(k_backward_sq_chunks, dim3(sg.n_slots), block, 0, s, p, b, sg);
+			if ((rc = fr_check_launch("k_backward_sq_chunks"))) return rc;
+			hipLaunchKernelGGL(k_backward_sq_prefix, dim3(p.T), block, 0, s, p, b, sg);
+			if ((rc = fr_check_launch("k_backward_sq_prefix"))) return rc;
+			// four workgroups per CU (34 KiB of LDS each; 512 / 768 workgroups: 230 / 205 us against 190 on the benchmark room)
+			const unsigned grid = sg.n_chunks / 4u + 1u < 1024u ? sg.n_chunks / 4u + 1u : 1024u;
+			hipLaunchKernelGGL(k_backward_sq_leaves, dim3(grid), block, 0, s, p, b, (const float*)rows, sg);
+			return fr_check_launch("k_backward_sq_leaves");
+		}
 		hipLaunchKernelGGL(k_backward_sq_walk, dim3(p.T), block, 0, s, p, b, (const float*)rows);
 		return fr_check_launch("k_backward_sq_walk");
 	}

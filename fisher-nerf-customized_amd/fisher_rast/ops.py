@@ -151,9 +151,10 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
 
 def rasterize_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer,
-                       R, binningBuffer, imageBuffer, power, opacities=None):
+                       R, binningBuffer, imageBuffer, power, opacities=None, segmented=True):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196): returns
-    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+    `segmented=False` withholds the scratch buffer of the power-2 backward (tests: the single-pass walk)."""
     _need_gpu(means3D, "means3D")
     dev = means3D.device
     lib = _lib.load()
@@ -176,12 +177,16 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
         opac = _prep(opacities, dev) if opacities is not None else None
         cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, False, bg, view, proj, cpos)
         g = _gaussians(means3D, colors, sh_t, opac, scales, rotations, cov3D_precomp)
+        # power 2 on an image of few tiles: scratch for the segmented walk (fisher_rast.h, fr_backward_ws)
+        nscr = int(lib.fr_backward_scratch_bytes(P, W, H, int(power), int(R))) if segmented else 0
+        scratch = torch.empty((nscr,), dtype=torch.uint8, device=dev) if nscr else None
         with torch.cuda.device(dev):
-            _lib.check(lib.fr_backward(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
-                                       binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), int(power),
-                                       _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D),
-                                       _ptr(dL_dcov3D), _ptr(dL_dsh) if M > 0 else None, _ptr(dL_dscales),
-                                       _ptr(dL_drotations), _ptr(dL_dconic), _stream(dev)), "fr_backward")
+            _lib.check(lib.fr_backward_ws(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
+                                          binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), int(power),
+                                          _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D),
+                                          _ptr(dL_dcov3D), _ptr(dL_dsh) if M > 0 else None, _ptr(dL_dscales),
+                                          _ptr(dL_drotations), _ptr(dL_dconic), int(R), scratch.data_ptr() if nscr else None, nscr,
+                                          _stream(dev)), "fr_backward")
     else:
         for t in (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations):
             t.zero_()

@@ -132,6 +132,21 @@ int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* 
                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
                 fr_stream_t stream);
 
+/* fr_backward with a scratch buffer the power-2 backward may use: fr_backward_scratch_bytes(P, W, H, power, num_rendered) bytes,
+ * num_rendered = what fr_forward reported for this image (status[0]); 0 = no use for one (power 1, or more than 1024 tiles).
+ * With few tiles -- one 256 x 256 view is 256 workgroups on 256 CUs -- the longest tile list sets the time of the literal
+ * `backward_power=2` loop (models/SLAM/gaussian.py:1548-1549); given the scratch, the backward is cut into chunks of at most 64
+ * candidates of one 16 x 4 pixel strip that run as independent pieces of work (a cheap pass leaves each chunk's effect on a pixel's
+ * back-to-front state, a prefix pass the state in front of every chunk).  The same pairs contribute; a pixel's state at the start of a
+ * chunk differs from the single pass's by rounding only (a few 1e-7 relative).  scratch == NULL or too small: fr_backward's single pass. */
+size_t fr_backward_scratch_bytes(int32_t P, int32_t W, int32_t H, int32_t power, int64_t num_rendered);
+int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                   const void* geom_ws, const void* binning_ws, const void* image_ws,
+                   const float* dL_dout_color, int32_t power,
+                   float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
+                   float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dconic,
+                   int64_t num_rendered, void* scratch, size_t scratch_bytes, fr_stream_t stream);
+
 /* ---- second feature image on the same geometry (training step) ------------------------
  * The reference's get_loss renders twice with identical means / scales / rotations / opacities / camera and different
  * colours: RGB, then (depth, 1, depth^2) for depth + silhouette (models/SLAM/gaussian.py:199-211,

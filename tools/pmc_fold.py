@@ -3,7 +3,7 @@ import collections, csv, sys
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0]
-    if not any(t in k for t in ("k_fisher", "k_sort", "k_preprocess", "k_scatter", "k_scan", "k_pack")):
+    if not any(t in k for t in ("k_fisher", "k_sort", "k_preprocess", "k_scatter", "k_scan", "k_pack", "k_backward", "k_render")):
         continue
     acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
