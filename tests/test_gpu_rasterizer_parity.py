@@ -244,6 +244,26 @@ def test_autograd_front_end_with_shs(gpu):
     assert torch.isfinite(t["scales"].grad).all() and torch.isfinite(t["rotations"].grad).all()
 
 
+def test_backward_through_depth_only_gives_zero_gradients(gpu):
+    """The reference's backward ignores the gradients of `radii` and `depth` (__init__.py:100-136 there); a loss on the depth image
+    alone therefore reaches the Gaussians as zeros, not as an error (autograd is told not to fill in the unused output gradients)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings
+    P = 500
+    sc = random_scene(P, 43)
+    t = {k: torch.tensor(v, device=gpu, requires_grad=True) for k, v in sc.items()}
+    eye = torch.eye(4, device=gpu)
+    proj = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1.0001, 1], [0, 0, -0.01, 0]], dtype=torch.float32, device=gpu)
+    rs = GaussianRasterizationSettings(64, 64, 1.0, 1.0, torch.zeros(3, device=gpu), 1.0, eye, proj, 0, torch.zeros(3, device=gpu), False)
+    for power in (1, 2):
+        for v in t.values():
+            v.grad = None
+        im, radii, depth = GaussianRasterizer(rs, backward_power=power)(
+            means3D=t["means3D"], means2D=torch.zeros((P, 3), device=gpu, requires_grad=True), opacities=t["opacities"].reshape(-1, 1),
+            colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+        depth.sum().backward()
+        assert t["means3D"].grad is not None and not t["means3D"].grad.any() and not t["colors"].grad.any()
+
+
 def test_prefiltered_with_a_culled_point_is_an_error(gpu):
     """auxiliary.h:156-160: with `prefiltered` set, a point behind the near plane makes the reference print "Point is filtered
     although prefiltered is set" and trap the device.  Here the forward raises with that message and the device stays usable;
