@@ -5577,10 +5577,10 @@ __device__ __forceinline__ float fr_sq_update(FrSqPix& st, float alpha, const fl
 	return da;
 }
 
-// Few tiles (one view of 256 x 256 is 256 workgroups on 256 CUs): the longest list sets the time of k_backward_sq_walk, and a splat
-// that covers a strip puts all 64 pixel-lanes on ONE of its LDS accumulators (ds_add_f64 on one address: 192 cycles; 25 of them per
-// step).  With a scratch buffer (fr_backward_ws) the backward of such an image is cut into CHUNKS of at most 64 candidates of one
-// strip, each an independent piece of work:
+// k_backward_sq_walk is one workgroup per tile (one view of 256 x 256: 256 workgroups on 256 CUs, the longest list sets the time), and
+// a splat that covers a strip puts all 64 pixel-lanes on ONE of its LDS accumulators (ds_add_f64 on one address: 192 cycles; 25 of
+// them per step) -- at every image size.  With a scratch buffer (fr_backward_ws) the backward is cut into CHUNKS of at most 64
+// candidates of one strip, each an independent piece of work:
 //   k_backward_sq_slots    per tile: which segments of L keys (L = a third of the mean list length, >= 256, a multiple of 64) hold a
 //                          contributor of some pixel; segment k of tile t has slot floor(tile_off[t] / L) + t + k (unique, no prefix pass)
 //   k_backward_sq_chunks   per (tile, segment), a wave per strip: the candidates of the segment, back to front, 64 at a time; every
@@ -6811,7 +6811,8 @@ extern "C" int fr_forward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 // Scratch of the chunked power-2 backward (k_backward_sq_slots / _chunks / _prefix / _leaves).  With R tile instances and T tiles:
 // L = max(256, a third of the mean list length rounded up to 64) keys per segment, at most R / L + T + 1 segment slots, L / 64 chunk
 // slots per (segment, strip); per chunk slot its candidate list (512 B) and nine floats per pixel-lane (2304 B).
-#define FR_SQ_SEG_MAX_TILES 1024     // beyond (a 512 x 512 image) the tiles alone fill the CUs
+#define FR_SQ_SEG_MAX_TILES 16384    // (2048 x 2048; the chunked form wins at every size measured: 2.0-3.9x from 128 x 128 to 1200 x 680, tools/backward_p2_bench.py)
+#define FR_SQ_MAX_SCRATCH (4ull << 30)
 struct FrSqScratch { size_t slot_map, ctl, cnt, work, ctodo, list, pixmask, summ, bytes; uint32_t n_slots, n_chunks; };
 static FrSqScratch fr_sq_scratch(int64_t T, int64_t R)
 {
@@ -6836,7 +6837,8 @@ extern "C" size_t fr_backward_scratch_bytes(int32_t P, int32_t W, int32_t H, int
 	if (P <= 0 || W <= 0 || H <= 0 || power != 2 || num_rendered <= 0 || num_rendered > 0x7fffffffll) return 0;
 	const int64_t T = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
 	if (T > FR_SQ_SEG_MAX_TILES) return 0;
-	return fr_sq_scratch(T, num_rendered).bytes;
+	const size_t bytes = fr_sq_scratch(T, num_rendered).bytes;
+	return bytes <= FR_SQ_MAX_SCRATCH ? bytes : 0;
 }
 
 extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,

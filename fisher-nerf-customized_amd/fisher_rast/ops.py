@@ -149,6 +149,26 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
     return num_rendered, out_color, radii, geom, binning, img, out_depth
 
 
+_bwd_scratch = {}
+
+
+def _backward_scratch(dev, nbytes):
+    """The scratch of the chunked power-2 backward, kept per (device, stream) and only ever grown: 56 MB for a 256 x 256 view of the
+    benchmark room, 0.5 GB for 2M Gaussians at 512 x 512 -- a fresh `torch.empty` of that size per call sent the caching allocator
+    through free / malloc cycles when image sizes alternate (1.8 ms per call instead of 0.45).  `release_backward_scratch()` drops it."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
+    t = _bwd_scratch.get(key)
+    if t is None or t.numel() < nbytes:
+        _bwd_scratch[key] = None
+        t = torch.empty((nbytes + (nbytes >> 2),), dtype=torch.uint8, device=dev)
+        _bwd_scratch[key] = t
+    return t
+
+
+def release_backward_scratch():
+    _bwd_scratch.clear()
+
+
 def rasterize_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer,
                        R, binningBuffer, imageBuffer, power, opacities=None, segmented=True):
@@ -177,15 +197,16 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
         opac = _prep(opacities, dev) if opacities is not None else None
         cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, False, bg, view, proj, cpos)
         g = _gaussians(means3D, colors, sh_t, opac, scales, rotations, cov3D_precomp)
-        # power 2 on an image of few tiles: scratch for the segmented walk (fisher_rast.h, fr_backward_ws)
+        # power 2 on an image of few tiles: scratch for the chunked backward (fisher_rast.h, fr_backward_ws)
         nscr = int(lib.fr_backward_scratch_bytes(P, W, H, int(power), int(R))) if segmented else 0
-        scratch = torch.empty((nscr,), dtype=torch.uint8, device=dev) if nscr else None
+        scratch = _backward_scratch(dev, nscr) if nscr else None
         with torch.cuda.device(dev):
             _lib.check(lib.fr_backward_ws(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
                                           binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), int(power),
                                           _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D),
                                           _ptr(dL_dcov3D), _ptr(dL_dsh) if M > 0 else None, _ptr(dL_dscales),
-                                          _ptr(dL_drotations), _ptr(dL_dconic), int(R), scratch.data_ptr() if nscr else None, nscr,
+                                          _ptr(dL_drotations), _ptr(dL_dconic), int(R), scratch.data_ptr() if nscr else None,
+                                          scratch.numel() if nscr else 0,
                                           _stream(dev)), "fr_backward")
     else:
         for t in (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations):

@@ -133,9 +133,10 @@ int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* 
                 fr_stream_t stream);
 
 /* fr_backward with a scratch buffer the power-2 backward may use: fr_backward_scratch_bytes(P, W, H, power, num_rendered) bytes,
- * num_rendered = what fr_forward reported for this image (status[0]); 0 = no use for one (power 1, or more than 1024 tiles).
- * With few tiles -- one 256 x 256 view is 256 workgroups on 256 CUs -- the longest tile list sets the time of the literal
- * `backward_power=2` loop (models/SLAM/gaussian.py:1548-1549); given the scratch, the backward is cut into chunks of at most 64
+ * num_rendered = what fr_forward reported for this image (status[0]); 0 = no use for one (power 1; more than 16384 tiles or 4 GiB).
+ * fr_backward's power-2 pass is one workgroup per tile -- one 256 x 256 view is 256 workgroups on 256 CUs, the longest tile list sets
+ * the time of the literal `backward_power=2` loop (models/SLAM/gaussian.py:1548-1549) -- and its per-candidate LDS accumulators
+ * serialise under splats that cover a strip; given the scratch, the backward is cut into chunks of at most 64
  * candidates of one 16 x 4 pixel strip that run as independent pieces of work (a cheap pass leaves each chunk's effect on a pixel's
  * back-to-front state, a prefix pass the state in front of every chunk).  The same pairs contribute; a pixel's state at the start of a
  * chunk differs from the single pass's by rounding only (a few 1e-7 relative).  scratch == NULL or too small: fr_backward's single pass. */

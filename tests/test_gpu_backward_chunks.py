@@ -37,7 +37,7 @@ def _room(P, W, H, seed):
                 scales=act["scales"].numpy(), rotations=act["rotations"].numpy())
 
 
-@pytest.mark.parametrize("P,W,H,bg", [(200_000, 256, 256, 0.0), (60_000, 128, 96, 0.3), (500_000, 256, 256, 0.0), (120_000, 250, 130, 1.0)])
+@pytest.mark.parametrize("P,W,H,bg", [(200_000, 256, 256, 0.0), (60_000, 128, 96, 0.3), (500_000, 256, 256, 0.0), (120_000, 250, 130, 1.0), (600_000, 800, 560, 0.0)])
 def test_chunks_match_the_single_pass(gpu, oracle, P, W, H, bg):
     from fisher_rast.synthetic import intrinsics
     sc = _room(P, W, H, 2)
