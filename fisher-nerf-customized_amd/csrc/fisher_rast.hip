@@ -6063,11 +6063,45 @@ __device__ __forceinline__ float fr_reduce_scatter32(float (&v)[32], int lane)
 	return h + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(h), 0xB1, 0xf, 0xf, false));                 // quad_perm [1,0,3,2]
 }
 
+// The same for 16 values: lane l returns the total of v[l >> 2].
+__device__ __forceinline__ float fr_reduce_scatter16(float (&v)[16], int lane)
+{
+	float s[8], t[4], r[2];
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+	{
+		const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 8]), false, false);
+		s[k] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+	{
+		const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 4]), false, false);
+		t[k] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+	}
+	const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+	for (int k = 0; k < 2; k++)
+	{
+		const float keep = b3 ? t[k + 2] : t[k], send = b3 ? t[k] : t[k + 2];
+		r[k] = keep + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(send), 0x128, 0xf, 0xf, false));     // row_ror:8
+	}
+	const float keep = b2 ? r[1] : r[0], send = b2 ? r[0] : r[1];
+	const int o = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)__float_as_uint(send), 0x1B, 0xf, 0xf, false), 0x141, 0xf, 0xf, false);   // lane ^ 4
+	float h = keep + __uint_as_float((uint32_t)o);
+	h = h + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(h), 0x4E, 0xf, 0xf, false));                   // quad_perm [2,3,0,1]
+	return h + __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(h), 0xB1, 0xf, 0xf, false));                // quad_perm [1,0,3,2]
+}
+
+// POW = 2: the 25 squared leaves (rows from k_backward_sq_rows).  POW = 1 (training): the nine sums k_backward_lin_walk keeps per
+// candidate -- screen-space mean 2, conic 3, colour 3, opacity 1 -- which k_backward_finish then pushes through the Jacobian chain;
+// no rows, 6 KiB of LDS.
+template <int POW>
 __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p, FrBwdArgs b, const float* __restrict__ rows, FrSqSegArgs sg)
 {
 	constexpr int NR4 = FR_SQ_ROWS / 4;
 	__shared__ float4 s_ent[4][32][3];            // half a chunk at a time: 34 KiB per workgroup, four workgroups per CU
-	__shared__ float4 s_rows[4][NR4][32];         // the leaf rows, [float4 of the row block][candidate]: written by LDS-direct loads
+	__shared__ float4 s_rows[4][POW == 2 ? NR4 : 1][32];      // the leaf rows, [float4 of the row block][candidate]: written by LDS-direct loads
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -6077,12 +6111,12 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 	const size_t HW = (size_t)p.H * p.W;
 	const float hw = (float)(0.5 * p.W), hh = (float)(0.5 * p.H);
 
-	// where this lane's total goes: lane 2 l holds leaf l (fr_reduce_scatter32); leaves in FR_SQ_NL order
+	// where this lane's total goes: lane 2 l holds leaf l (fr_reduce_scatter32; POW = 1: lane 4 l, fr_reduce_scatter16); leaves in FR_SQ_NL order
 	float* dst = nullptr;
 	uint32_t dstride = 0;
 	{
-		const int l = lane >> 1;
-		if (!(lane & 1) && l < FR_SQ_NL)
+		const int l = POW == 2 ? lane >> 1 : lane >> 2;
+		if ((lane & (POW == 2 ? 1 : 3)) == 0 && l < (POW == 2 ? FR_SQ_NL : 9))
 		{
 			if (l < 2) { dst = b.dL_dmean2D + l; dstride = 3; }
 			else if (l < 5) { dst = b.dL_dconic + (l == 4 ? 3 : l - 2); dstride = 4; }
@@ -6141,6 +6175,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 					ent[e][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(my_pos));
 					ent[e][2] = make_float4(b.colors[3 * (size_t)my_id], b.colors[3 * (size_t)my_id + 1], b.colors[3 * (size_t)my_id + 2], 0.f);
 				}
+				if constexpr (POW == 2)
 				{
 					// the 224 bytes of leaf rows of the 32 candidates, global memory -> LDS with no register in between (through registers the
 					// compiler waits for each of the fourteen loads in turn): one instruction moves float4 2 kk of the 32 candidates on lanes
@@ -6163,55 +6198,81 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 					const bool ok = ((mask >> jj) & 1ull) != 0ull && fr_sq_test(r0, r1, pfx, pfy, ncontrib, dx, dy, G, alpha);
 					if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
 					const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
-					float w = 0.f, wcol = 0.f;
-					if (ok)
+					float tot;
+					if constexpr (POW == 2)
 					{
-						// backward.cu:978-1038
-						float da = fr_sq_update(st, alpha, r2, g);
-						wcol = alpha * st.Tc;
-						if (bg_dot != 0.f) da += (-T_final / (1.f - alpha)) * bg_dot;
-						w = (o * da) * G;                                              // dL_dG * G
-					}
-					// from here on every lane executes: a lane without the pair carries w = wcol = 0, so all its squares are 0
-					const float ux = -(cx * dx + cy * dy), uy = -(cy * dx + cz * dy);   // u = -conic d
-					const float uxx = ux * ux, uxy = ux * uy, uyy = uy * uy;
-					float v[32];
-					{
-						const float l0 = w * ux * hw, l1 = w * uy * hh;                                   // dL_dmean2D (backward.cu:1021-1024)
-						const float hq = -0.5f * w;
-						const float l2 = hq * dx * dx, l3 = hq * dx * dy, l4 = hq * dy * dy;               // dL_dconic x, y, w (1026-1029)
-						v[0] = l0 * l0; v[1] = l1 * l1; v[2] = l2 * l2; v[3] = l3 * l3; v[4] = l4 * l4;
-					}
+						float w = 0.f, wcol = 0.f;
+						if (ok)
+						{
+							// backward.cu:978-1038
+							float da = fr_sq_update(st, alpha, r2, g);
+							wcol = alpha * st.Tc;
+							if (bg_dot != 0.f) da += (-T_final / (1.f - alpha)) * bg_dot;
+							w = (o * da) * G;                                              // dL_dG * G
+						}
+						// from here on every lane executes: a lane without the pair carries w = wcol = 0, so all its squares are 0
+						const float ux = -(cx * dx + cy * dy), uy = -(cy * dx + cz * dy);   // u = -conic d
+						const float uxx = ux * ux, uxy = ux * uy, uyy = uy * uy;
+						float v[32];
+						{
+							const float l0 = w * ux * hw, l1 = w * uy * hh;                                   // dL_dmean2D (backward.cu:1021-1024)
+							const float hq = -0.5f * w;
+							const float l2 = hq * dx * dx, l3 = hq * dx * dy, l4 = hq * dy * dy;               // dL_dconic x, y, w (1026-1029)
+							v[0] = l0 * l0; v[1] = l1 * l1; v[2] = l2 * l2; v[3] = l3 * l3; v[4] = l4 * l4;
+						}
 #pragma unroll
-					for (int c = 0; c < 3; c++) { const float l = wcol * g[c]; v[5 + c] = l * l; }         // dL_dcolors
-					{
-						const float4 rz = rws[13][j];                                                     // rows[52..55]: {.., .., 1 / opacity^2, pad}
-						v[8] = w * w * rz.z;                                                               // dL_dopacity = G dL_dalpha = w / opacity
-					}
-					// the 16 rows: mean 3 x 5, then cov3D 6 x 3 and scale / rotation 7 x 3 over (ux^2, ux uy, uy^2), applied to w gamma
-					float rf[FR_SQ_ROWS];
+						for (int c = 0; c < 3; c++) { const float l = wcol * g[c]; v[5 + c] = l * l; }         // dL_dcolors
+						{
+							const float4 rz = rws[13][j];                                                     // rows[52..55]: {.., .., 1 / opacity^2, pad}
+							v[8] = w * w * rz.z;                                                               // dL_dopacity = G dL_dalpha = w / opacity
+						}
+						// the 16 rows: mean 3 x 5, then cov3D 6 x 3 and scale / rotation 7 x 3 over (ux^2, ux uy, uy^2), applied to w gamma
+						float rf[FR_SQ_ROWS];
 #pragma unroll
-					for (int k = 0; k < NR4; k++)
-					{
-						const float4 t = rws[k][j];
-						rf[4 * k] = t.x; rf[4 * k + 1] = t.y; rf[4 * k + 2] = t.z; rf[4 * k + 3] = t.w;
-					}
-					const float g0 = w * ux, g1 = w * uy, g2 = w * uxx, g3 = w * uxy, g4 = w * uyy;
+						for (int k = 0; k < NR4; k++)
+						{
+							const float4 t = rws[k][j];
+							rf[4 * k] = t.x; rf[4 * k + 1] = t.y; rf[4 * k + 2] = t.z; rf[4 * k + 3] = t.w;
+						}
+						const float g0 = w * ux, g1 = w * uy, g2 = w * uxx, g3 = w * uxy, g4 = w * uyy;
 #pragma unroll
-					for (int r = 0; r < 3; r++)
-					{
-						const float l = rf[r * 5] * g0 + rf[r * 5 + 1] * g1 + rf[r * 5 + 2] * g2 + rf[r * 5 + 3] * g3 + rf[r * 5 + 4] * g4;
-						v[9 + r] = l * l;
-					}
+						for (int r = 0; r < 3; r++)
+						{
+							const float l = rf[r * 5] * g0 + rf[r * 5 + 1] * g1 + rf[r * 5 + 2] * g2 + rf[r * 5 + 3] * g3 + rf[r * 5 + 4] * g4;
+							v[9 + r] = l * l;
+						}
 #pragma unroll
-					for (int r = 0; r < 13; r++)
-					{
-						const float l = rf[15 + r * 3] * g2 + rf[15 + r * 3 + 1] * g3 + rf[15 + r * 3 + 2] * g4;
-						v[12 + r] = l * l;
-					}
+						for (int r = 0; r < 13; r++)
+						{
+							const float l = rf[15 + r * 3] * g2 + rf[15 + r * 3 + 1] * g3 + rf[15 + r * 3 + 2] * g4;
+							v[12 + r] = l * l;
+						}
 #pragma unroll
-					for (int k = FR_SQ_NL; k < 32; k++) v[k] = 0.f;
-					const float tot = fr_reduce_scatter32(v, lane);
+						for (int k = FR_SQ_NL; k < 32; k++) v[k] = 0.f;
+						tot = fr_reduce_scatter32(v, lane);
+					}
+					else
+					{
+						// backward.cu:978-1038: the terms of k_backward_lin_walk, zero on a lane without the pair
+						float dL_dalpha = 0.f, wcol = 0.f;
+						if (ok)
+						{
+							dL_dalpha = fr_sq_update(st, alpha, r2, g);
+							wcol = alpha * st.Tc;
+							if (bg_dot != 0.f) dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+						}
+						const float dL_dG = o * dL_dalpha;
+						const float gdx = G * dx, gdy = G * dy;
+						const float dG_ddelx = -gdx * cx - gdy * cy, dG_ddely = -gdy * cz - gdx * cy;
+						float v[16];
+						v[0] = dL_dG * dG_ddelx * hw; v[1] = dL_dG * dG_ddely * hh;
+						v[2] = -0.5f * gdx * dx * dL_dG; v[3] = -0.5f * gdx * dy * dL_dG; v[4] = -0.5f * gdy * dy * dL_dG;
+						v[5] = wcol * g[0]; v[6] = wcol * g[1]; v[7] = wcol * g[2];
+						v[8] = G * dL_dalpha;
+#pragma unroll
+						for (int k = 9; k < 16; k++) v[k] = 0.f;
+						tot = fr_reduce_scatter16(v, lane);
+					}
 					const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, jj);
 					if (dst != nullptr && tot != 0.f) atomicAdd(dst + (size_t)id * dstride, tot);
 				}
@@ -6834,7 +6895,7 @@ static FrSqScratch fr_sq_scratch(int64_t T, int64_t R)
 }
 extern "C" size_t fr_backward_scratch_bytes(int32_t P, int32_t W, int32_t H, int32_t power, int64_t num_rendered)
 {
-	if (P <= 0 || W <= 0 || H <= 0 || power != 2 || num_rendered <= 0 || num_rendered > 0x7fffffffll) return 0;
+	if (P <= 0 || W <= 0 || H <= 0 || (power != 1 && power != 2) || num_rendered <= 0 || num_rendered > 0x7fffffffll) return 0;
 	const int64_t T = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
 	if (T > FR_SQ_SEG_MAX_TILES) return 0;
 	const size_t bytes = fr_sq_scratch(T, num_rendered).bytes;
@@ -6871,8 +6932,9 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 	const bool sq_rows_path = power == 2 && g->scales && !g->shs && g->colors_precomp && !g->cov3D_precomp && fr_debug_mode() != 21;
 	const int64_t T_img = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
 	// few tiles and a scratch buffer: the chunked form (FR_DEBUG_MODE=33 in the rig: one workgroup per tile whatever the scratch)
-	const size_t scratch_need = sq_rows_path ? fr_backward_scratch_bytes(P, W, H, 2, num_rendered) : 0;
-	const bool segmented = sq_rows_path && scratch && scratch_need > 0 && scratch_bytes >= scratch_need FR_AB_ONLY(&& fr_debug_mode() != 33);
+	const bool chunk_path = sq_rows_path || (power == 1 FR_AB_ONLY(&& fr_debug_mode() != 17));
+	const size_t scratch_need = chunk_path ? fr_backward_scratch_bytes(P, W, H, power, num_rendered) : 0;
+	const bool segmented = chunk_path && scratch && scratch_need > 0 && scratch_bytes >= scratch_need FR_AB_ONLY(&& fr_debug_mode() != 33);
 	const FrSqScratch sq = fr_sq_scratch(T_img, segmented ? num_rendered : 1);
 	{
 		FrZeroer z;
@@ -6903,6 +6965,29 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 	b.only_flagged = nullptr;
 	b.u_only = 0;
 	b.dL_dmean2D_b = nullptr;
+	// the chunked form (k_backward_sq_slots ... _leaves); the kernels size their segments from status[0], num_rendered must be that
+	// number: the scratch layout depends on it
+	auto launch_chunked = [&](const float* rows) -> int {
+		FrSqSegArgs sg;
+		char* sc = (char*)scratch;
+		sg.slot_map = (uint32_t*)(sc + sq.slot_map); sg.ctl = (uint32_t*)(sc + sq.ctl); sg.cnt = (uint32_t*)(sc + sq.cnt);
+		sg.work = (uint2*)(sc + sq.work); sg.ctodo = (uint2*)(sc + sq.ctodo); sg.pixmask = (uint2*)(sc + sq.pixmask);
+		sg.list = (uint2*)(sc + sq.list); sg.summ = (float*)(sc + sq.summ);
+		sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks;
+		int rc2;
+		hipLaunchKernelGGL(k_backward_sq_slots, dim3(p.T), block, 0, s, p, b, sg);
+		if ((rc2 = fr_check_launch("k_backward_sq_slots"))) return rc2;
+		hipLaunchKernelGGL(k_backward_sq_chunks, dim3(sg.n_slots), block, 0, s, p, b, sg);
+		if ((rc2 = fr_check_launch("k_backward_sq_chunks"))) return rc2;
+		hipLaunchKernelGGL(k_backward_sq_prefix, dim3(p.T), block, 0, s, p, b, sg);
+		if ((rc2 = fr_check_launch("k_backward_sq_prefix"))) return rc2;
+		// power 2: four workgroups per CU (34 KiB of LDS each; 512 / 768 workgroups: 230 / 205 us against 190 on the benchmark room)
+		const unsigned cap = rows ? 1024u : 2048u;
+		const unsigned grid = sg.n_chunks / 4u + 1u < cap ? sg.n_chunks / 4u + 1u : cap;
+		if (rows) hipLaunchKernelGGL((k_backward_sq_leaves<2>), dim3(grid), block, 0, s, p, b, rows, sg);
+		else hipLaunchKernelGGL((k_backward_sq_leaves<1>), dim3(grid), block, 0, s, p, b, rows, sg);
+		return fr_check_launch("k_backward_sq_leaves");
+	};
 	if (power == 1)
 	{
 		// gradients: sum u per splat in the tile kernel, Jacobian chain once per Gaussian; tiles that do not fit the LDS
@@ -6925,6 +7010,12 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 		}
 		else
 #endif
+		if (segmented)
+		{
+			if ((rc = launch_chunked(nullptr))) return rc;
+			b.u_only = 1;
+		}
+		else
 		{
 			hipLaunchKernelGGL((k_backward_lin_walk<false>), dim3(p.T), block, 0, s, p, b);
 			if ((rc = fr_check_launch("k_backward_lin_walk"))) return rc;
@@ -6945,26 +7036,7 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 		float* rows = (float*)((char*)geom_ws + L.packed);           // [P][56] floats of the geometry buffer's 256-byte-per-Gaussian region
 		hipLaunchKernelGGL(k_backward_sq_rows, dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, rows);
 		if ((rc = fr_check_launch("k_backward_sq_rows"))) return rc;
-		if (segmented)
-		{
-			// (the kernels size their segments from status[0]; num_rendered must be that number: the layout above depends on it)
-			FrSqSegArgs sg;
-			char* sc = (char*)scratch;
-			sg.slot_map = (uint32_t*)(sc + sq.slot_map); sg.ctl = (uint32_t*)(sc + sq.ctl); sg.cnt = (uint32_t*)(sc + sq.cnt);
-			sg.work = (uint2*)(sc + sq.work); sg.ctodo = (uint2*)(sc + sq.ctodo); sg.pixmask = (uint2*)(sc + sq.pixmask);
-			sg.list = (uint2*)(sc + sq.list); sg.summ = (float*)(sc + sq.summ);
-			sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks;
-			hipLaunchKernelGGL(k_backward_sq_slots, dim3(p.T), block, 0, s, p, b, sg);
-			if ((rc = fr_check_launch("k_backward_sq_slots"))) return rc;
-			hipLaunchKernelGGL(k_backward_sq_chunks, dim3(sg.n_slots), block, 0, s, p, b, sg);
-			if ((rc = fr_check_launch("k_backward_sq_chunks"))) return rc;
-			hipLaunchKernelGGL(k_backward_sq_prefix, dim3(p.T), block, 0, s, p, b, sg);
-			if ((rc = fr_check_launch("k_backward_sq_prefix"))) return rc;
-			// four workgroups per CU (34 KiB of LDS each; 512 / 768 workgroups: 230 / 205 us against 190 on the benchmark room)
-			const unsigned grid = sg.n_chunks / 4u + 1u < 1024u ? sg.n_chunks / 4u + 1u : 1024u;
-			hipLaunchKernelGGL(k_backward_sq_leaves, dim3(grid), block, 0, s, p, b, (const float*)rows, sg);
-			return fr_check_launch("k_backward_sq_leaves");
-		}
+		if (segmented) return launch_chunked((const float*)rows);
 		hipLaunchKernelGGL(k_backward_sq_walk, dim3(p.T), block, 0, s, p, b, (const float*)rows);
 		return fr_check_launch("k_backward_sq_walk");
 	}

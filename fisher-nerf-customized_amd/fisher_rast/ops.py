@@ -197,7 +197,7 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
         opac = _prep(opacities, dev) if opacities is not None else None
         cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, False, bg, view, proj, cpos)
         g = _gaussians(means3D, colors, sh_t, opac, scales, rotations, cov3D_precomp)
-        # power 2 on an image of few tiles: scratch for the chunked backward (fisher_rast.h, fr_backward_ws)
+        # scratch for the chunked backward (fisher_rast.h, fr_backward_ws; power 1 and 2)
         nscr = int(lib.fr_backward_scratch_bytes(P, W, H, int(power), int(R))) if segmented else 0
         scratch = _backward_scratch(dev, nscr) if nscr else None
         with torch.cuda.device(dev):
