@@ -5577,6 +5577,26 @@ __device__ __forceinline__ float fr_sq_update(FrSqPix& st, float alpha, const fl
 	return da;
 }
 
+// The same for NCH colour channels (3: one image; 6: the image pair of fr_backward_pair -- channels 3-5 belong to the second image,
+// whose dL_dalpha comes back in db); the statements of fr_sq_update, channel by channel.
+template <int NCH> struct FrBwdPixT { float Tc, last_alpha, accum[NCH], lastc[NCH]; };
+template <int NCH>
+__device__ __forceinline__ void fr_bwd_update(FrBwdPixT<NCH>& st, float alpha, const float (&rc)[NCH], const float (&g)[NCH], float& da, float& db)
+{
+	st.Tc = st.Tc / (1.f - alpha);
+	da = 0.f; db = 0.f;
+#pragma unroll
+	for (int c = 0; c < NCH; c++)
+	{
+		st.accum[c] = st.last_alpha * st.lastc[c] + (1.f - st.last_alpha) * st.accum[c];
+		st.lastc[c] = rc[c];
+		const float t = (rc[c] - st.accum[c]) * g[c];
+		if (c < 3) da += t; else db += t;
+	}
+	da *= st.Tc; db *= st.Tc;
+	st.last_alpha = alpha;
+}
+
 // k_backward_sq_walk is one workgroup per tile (one view of 256 x 256: 256 workgroups on 256 CUs, the longest list sets the time), and
 // a splat that covers a strip puts all 64 pixel-lanes on ONE of its LDS accumulators (ds_add_f64 on one address: 192 cycles; 25 of
 // them per step) -- at every image size.  With a scratch buffer (fr_backward_ws) the backward is cut into CHUNKS of at most 64
@@ -5644,24 +5664,29 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_slots(FrParams p, Fr
 		if (slot0 + k < sg.n_slots) sg.slot_map[slot0 + k] = tile + 1u;
 }
 
-// The map of one chunk on one pixel's state, built contributor by contributor (back to front)
-struct FrSqMap { float Pq, A, B[3], la, lc[3]; };      // la < 0: no contributor, the identity
-__device__ __forceinline__ void fr_sq_map_step(FrSqMap& mp, float alpha, const float4& r2)
+// The map of one chunk on one pixel's state, built contributor by contributor (back to front); 3 + 2 NCH floats
+template <int NCH> struct FrBwdMapT { float Pq, A, la, B[NCH], lc[NCH]; };      // la < 0: no contributor, the identity
+template <int NCH>
+__device__ __forceinline__ void fr_bwd_map_step(FrBwdMapT<NCH>& mp, float alpha, const float (&rc)[NCH])
 {
 	if (mp.la >= 0.f)
 	{
 		const float k = 1.f - mp.la;
-		mp.B[0] = mp.la * mp.lc[0] + k * mp.B[0]; mp.B[1] = mp.la * mp.lc[1] + k * mp.B[1]; mp.B[2] = mp.la * mp.lc[2] + k * mp.B[2];
+#pragma unroll
+		for (int c = 0; c < NCH; c++) mp.B[c] = mp.la * mp.lc[c] + k * mp.B[c];
 		mp.A = k * mp.A;
 	}
 	mp.Pq = mp.Pq / (1.f - alpha);
-	mp.la = alpha; mp.lc[0] = r2.x; mp.lc[1] = r2.y; mp.lc[2] = r2.z;
+	mp.la = alpha;
+#pragma unroll
+	for (int c = 0; c < NCH; c++) mp.lc[c] = rc[c];
 }
-__device__ __forceinline__ void fr_sq_map_apply(FrSqPix& st, const FrSqMap& mp)
+template <int NCH>
+__device__ __forceinline__ void fr_bwd_map_apply(FrBwdPixT<NCH>& st, const FrBwdMapT<NCH>& mp)
 {
 	if (!(mp.la >= 0.f)) return;
 #pragma unroll
-	for (int c = 0; c < 3; c++)
+	for (int c = 0; c < NCH; c++)
 	{
 		const float x = st.last_alpha * st.lastc[c] + (1.f - st.last_alpha) * st.accum[c];     // what the chunk's first contributor sees behind it
 		st.accum[c] = mp.B[c] + mp.A * x;                                                      // ... and its last one
@@ -5670,11 +5695,51 @@ __device__ __forceinline__ void fr_sq_map_apply(FrSqPix& st, const FrSqMap& mp)
 	st.Tc = st.Tc * mp.Pq;
 	st.last_alpha = mp.la;
 }
+// a map in the scratch buffer: rows of 64 lanes {Pq, A, B[NCH], la, lc[NCH]}; the state that replaces it {Tc, last alpha, accum[NCH], lastc[NCH]}
+template <int NCH> __device__ __forceinline__ void fr_bwd_map_store(float* sm, const FrBwdMapT<NCH>& mp)
+{
+	sm[0 * 64] = mp.Pq; sm[1 * 64] = mp.A; sm[(2 + NCH) * 64] = mp.la;
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { sm[(2 + c) * 64] = mp.B[c]; sm[(3 + NCH + c) * 64] = mp.lc[c]; }
+}
+template <int NCH> __device__ __forceinline__ void fr_bwd_map_load(const float* sm, FrBwdMapT<NCH>& mp)
+{
+	mp.Pq = sm[0 * 64]; mp.A = sm[1 * 64]; mp.la = sm[(2 + NCH) * 64];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { mp.B[c] = sm[(2 + c) * 64]; mp.lc[c] = sm[(3 + NCH + c) * 64]; }
+}
+template <int NCH> __device__ __forceinline__ void fr_bwd_map_identity(FrBwdMapT<NCH>& mp)
+{
+	mp.Pq = 1.f; mp.A = 1.f; mp.la = -1.f;
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { mp.B[c] = 0.f; mp.lc[c] = 0.f; }
+}
+template <int NCH> __device__ __forceinline__ void fr_bwd_state_store(float* sm, const FrBwdPixT<NCH>& st)
+{
+	sm[0 * 64] = st.Tc; sm[1 * 64] = st.last_alpha;
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { sm[(2 + c) * 64] = st.accum[c]; sm[(2 + NCH + c) * 64] = st.lastc[c]; }
+}
+template <int NCH> __device__ __forceinline__ void fr_bwd_state_load(const float* sm, FrBwdPixT<NCH>& st)
+{
+	st.Tc = sm[0 * 64]; st.last_alpha = sm[1 * 64];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { st.accum[c] = sm[(2 + c) * 64]; st.lastc[c] = sm[(2 + NCH + c) * 64]; }
+}
+template <int NCH> __device__ __forceinline__ void fr_bwd_state_init(FrBwdPixT<NCH>& st, float T_final)
+{
+	st.Tc = T_final; st.last_alpha = 0.f;
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { st.accum[c] = 0.f; st.lastc[c] = 0.f; }
+}
+#define FR_BWD_MAP_FLOATS(NCH) (3 + 2 * (NCH))
 
+template <int NCH>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, FrBwdArgs b, FrSqSegArgs sg)
 {
 	__shared__ uint2 s_q[4][FR_QCAP];
-	__shared__ float4 s_ent[4][64][3];
+	constexpr int EF4 = NCH == 6 ? 4 : 3;
+	__shared__ float4 s_ent[4][64][EF4];
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -5692,7 +5757,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 	const uint64_t* gk = p.keys + p.tile_off[tile];
 	const float4* splat = (const float4*)p.splat;
 	uint2* wq = s_q[wave];
-	float4 (*ent)[3] = s_ent[wave];
+	float4 (*ent)[EF4] = s_ent[wave];
 	const uint32_t ncontrib = inside ? b.n_contrib[(size_t)p.W * pxy + pxx] : 0u;
 	const uint32_t seg_lo = seg_k * L;
 	const uint32_t seg_hi = seg_lo + L < n ? seg_lo + L : n;
@@ -5742,6 +5807,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 			ent[lane][0] = q0;
 			ent[lane][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(qe.y));
 			ent[lane][2] = make_float4(b.colors[3 * (size_t)qe.x], b.colors[3 * (size_t)qe.x + 1], b.colors[3 * (size_t)qe.x + 2], 0.f);
+			if constexpr (NCH == 6) ent[lane][3] = make_float4(b.colors2[3 * (size_t)qe.x], b.colors2[3 * (size_t)qe.x + 1], b.colors2[3 * (size_t)qe.x + 2], 0.f);
 			const float4 a = make_float4(q0.x, q0.y, q1.w, __builtin_amdgcn_logf(q1.y));
 			const float4 b4 = make_float4(-0.5f * q0.z, -q0.w, -0.5f * q1.x, 0.f);
 			emask = fr_footprint_mask<16, 4>(a, b4, strip_lo, tile_x0);
@@ -5758,10 +5824,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		FrSqMap mp;
-		mp.Pq = 1.f; mp.A = 1.f; mp.la = -1.f;
-#pragma unroll
-		for (int c = 0; c < 3; c++) { mp.B[c] = 0.f; mp.lc[c] = 0.f; }
+		FrBwdMapT<NCH> mp;
+		fr_bwd_map_identity(mp);
 		while (mask != 0ull)
 		{
 			const int j = __ffsll((long long)mask) - 1;
@@ -5769,13 +5833,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 			const float4 r0 = ent[j][0], r1 = ent[j][1], r2 = ent[j][2];
 			float dx, dy, G, alpha;
 			if (!fr_sq_test(r0, r1, pfx, pfy, ncontrib, dx, dy, G, alpha)) continue;
-			fr_sq_map_step(mp, alpha, r2);
+			float rc[NCH];
+			rc[0] = r2.x; rc[1] = r2.y; rc[2] = r2.z;
+			if constexpr (NCH == 6) { const float4 r3 = ent[j][3]; rc[3] = r3.x; rc[4] = r3.y; rc[5] = r3.z; }
+			fr_bwd_map_step(mp, alpha, rc);
 		}
 		if (room)
 		{
-			float* sm = sg.summ + cid * (9 * 64) + lane;
-			sm[0 * 64] = mp.Pq; sm[1 * 64] = mp.A; sm[2 * 64] = mp.B[0]; sm[3 * 64] = mp.B[1]; sm[4 * 64] = mp.B[2];
-			sm[5 * 64] = mp.la; sm[6 * 64] = mp.lc[0]; sm[7 * 64] = mp.lc[1]; sm[8 * 64] = mp.lc[2];
+			fr_bwd_map_store(sg.summ + cid * (FR_BWD_MAP_FLOATS(NCH) * 64) + lane, mp);
 			nchunk++;
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -5796,6 +5861,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 	}
 }
 
+template <int NCH>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_prefix(FrParams p, FrBwdArgs b, FrSqSegArgs sg)
 {
 	if (p.status[1]) return;
@@ -5808,10 +5874,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_prefix(FrParams p, F
 	const uint32_t n = p.tile_cnt[tile];
 	const uint32_t L = fr_sq_seg_length(p), cmax = L >> 6;
 	const uint32_t slot0 = p.tile_off[tile] / L + tile;
-	FrSqPix st;
-	st.Tc = inside ? b.final_T[(size_t)p.W * pxy + pxx] : 0.f; st.last_alpha = 0.f;
-#pragma unroll
-	for (int c = 0; c < 3; c++) { st.accum[c] = 0.f; st.lastc[c] = 0.f; }
+	FrBwdPixT<NCH> st;
+	fr_bwd_state_init(st, inside ? b.final_T[(size_t)p.W * pxy + pxx] : 0.f);
 	// segments from the back of the list, 64 at a time: lane i looks up segment kb - i, the wave then goes through them in order
 	for (int kb = (int)((n + L - 1u) / L) - 1; kb >= 0; kb -= 64)
 	{
@@ -5831,27 +5895,19 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_prefix(FrParams p, F
 			for (uint32_t c0 = 0; c0 < nc; c0 += 4u)
 			{
 				// the maps of up to four chunks first (independent loads), then the chain
-				FrSqMap mp[4];
+				FrBwdMapT<NCH> mp[4];
 #pragma unroll
 				for (int u = 0; u < 4; u++)
 				{
-					mp[u].la = -1.f; mp[u].Pq = 1.f; mp[u].A = 1.f;
-					mp[u].B[0] = mp[u].B[1] = mp[u].B[2] = 0.f; mp[u].lc[0] = mp[u].lc[1] = mp[u].lc[2] = 0.f;
-					if (c0 + (uint32_t)u < nc)
-					{
-						const float* sm = sg.summ + (cid0 + c0 + u) * (9 * 64) + lane;
-						mp[u].Pq = sm[0 * 64]; mp[u].A = sm[1 * 64]; mp[u].B[0] = sm[2 * 64]; mp[u].B[1] = sm[3 * 64]; mp[u].B[2] = sm[4 * 64];
-						mp[u].la = sm[5 * 64]; mp[u].lc[0] = sm[6 * 64]; mp[u].lc[1] = sm[7 * 64]; mp[u].lc[2] = sm[8 * 64];
-					}
+					fr_bwd_map_identity(mp[u]);
+					if (c0 + (uint32_t)u < nc) fr_bwd_map_load(sg.summ + (cid0 + c0 + u) * (FR_BWD_MAP_FLOATS(NCH) * 64) + lane, mp[u]);
 				}
 #pragma unroll
 				for (int u = 0; u < 4; u++)
 					if (c0 + (uint32_t)u < nc)
 					{
-						float* sm = sg.summ + (cid0 + c0 + u) * (9 * 64) + lane;
-						sm[0 * 64] = st.Tc; sm[1 * 64] = st.last_alpha; sm[2 * 64] = st.accum[0]; sm[3 * 64] = st.accum[1]; sm[4 * 64] = st.accum[2];
-						sm[5 * 64] = st.lastc[0]; sm[6 * 64] = st.lastc[1]; sm[7 * 64] = st.lastc[2];
-						fr_sq_map_apply(st, mp[u]);
+						fr_bwd_state_store(sg.summ + (cid0 + c0 + u) * (FR_BWD_MAP_FLOATS(NCH) * 64) + lane, st);
+						fr_bwd_map_apply(st, mp[u]);
 					}
 			}
 		}
@@ -6096,17 +6152,18 @@ __device__ __forceinline__ float fr_reduce_scatter16(float (&v)[16], int lane)
 // POW = 2: the 25 squared leaves (rows from k_backward_sq_rows).  POW = 1 (training): the nine sums k_backward_lin_walk keeps per
 // candidate -- screen-space mean 2, conic 3, colour 3, opacity 1 -- which k_backward_finish then pushes through the Jacobian chain;
 // no rows, 6 KiB of LDS.
-template <int POW>
+template <int POW, int NCH>
 __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p, FrBwdArgs b, const float* __restrict__ rows, FrSqSegArgs sg)
 {
-	constexpr int NR4 = FR_SQ_ROWS / 4;
-	__shared__ float4 s_ent[4][32][3];            // half a chunk at a time: 34 KiB per workgroup, four workgroups per CU
+	static_assert(POW == 1 || NCH == 3, "the power-2 leaves are those of one image");
+	constexpr int NR4 = FR_SQ_ROWS / 4, EF4 = NCH == 6 ? 4 : 3;
+	__shared__ float4 s_ent[4][32][EF4];            // half a chunk at a time: 34 KiB per workgroup, four workgroups per CU
 	__shared__ float4 s_rows[4][POW == 2 ? NR4 : 1][32];      // the leaf rows, [float4 of the row block][candidate]: written by LDS-direct loads
 	if (p.status[1]) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const float4* splat = (const float4*)p.splat;
-	float4 (*ent)[3] = s_ent[wave];
+	float4 (*ent)[EF4] = s_ent[wave];
 	float4 (*rws)[32] = s_rows[wave];
 	const size_t HW = (size_t)p.H * p.W;
 	const float hw = (float)(0.5 * p.W), hh = (float)(0.5 * p.H);
@@ -6116,11 +6173,19 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 	uint32_t dstride = 0;
 	{
 		const int l = POW == 2 ? lane >> 1 : lane >> 2;
-		if ((lane & (POW == 2 ? 1 : 3)) == 0 && l < (POW == 2 ? FR_SQ_NL : 9))
+		constexpr int NL = POW == 2 ? FR_SQ_NL : (NCH == 6 ? 14 : 9);
+		if ((lane & (POW == 2 ? 1 : 3)) == 0 && l < NL)
 		{
 			if (l < 2) { dst = b.dL_dmean2D + l; dstride = 3; }
 			else if (l < 5) { dst = b.dL_dconic + (l == 4 ? 3 : l - 2); dstride = 4; }
 			else if (l < 8) { dst = b.dL_dcolors + (l - 5); dstride = 3; }
+			else if constexpr (NCH == 6)
+			{
+				// the image pair: colours of the second image, opacity, the second image's screen-space mean
+				if (l < 11) { dst = b.dL_dcolors2 + (l - 8); dstride = 3; }
+				else if (l < 12) { dst = b.dL_dopacity; dstride = 1; }
+				else { dst = b.dL_dmean2D_2 + (l - 12); dstride = 3; }
+			}
 			else if (l < 9) { dst = b.dL_dopacity; dstride = 1; }
 			else if (l < 12) { dst = b.dL_dmean3D + (l - 9); dstride = 3; }
 			else if (l < 18) { dst = b.dL_dcov3D + (l - 12); dstride = 6; }
@@ -6147,15 +6212,19 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 			const size_t pix = (size_t)p.W * pxy + pxx;
 			const float T_final = inside ? b.final_T[pix] : 0.f;
 			const uint32_t ncontrib = inside ? b.n_contrib[pix] : 0u;
-			float g[3] = { 0.f, 0.f, 0.f };
-			if (inside) { g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix]; }
-			const float bg_dot = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
-			FrSqPix st;
+			float g[NCH];
+#pragma unroll
+			for (int c = 0; c < NCH; c++) g[c] = 0.f;
+			if (inside)
 			{
-				const float* sm = sg.summ + cid * (9 * 64) + lane;          // the state in front of the chunk (k_backward_sq_prefix)
-				st.Tc = sm[0 * 64]; st.last_alpha = sm[1 * 64]; st.accum[0] = sm[2 * 64]; st.accum[1] = sm[3 * 64]; st.accum[2] = sm[4 * 64];
-				st.lastc[0] = sm[5 * 64]; st.lastc[1] = sm[6 * 64]; st.lastc[2] = sm[7 * 64];
+				g[0] = b.dL_dpix[pix]; g[1] = b.dL_dpix[HW + pix]; g[2] = b.dL_dpix[2 * HW + pix];
+				if constexpr (NCH == 6) { g[3] = b.dL_dpix2[pix]; g[4] = b.dL_dpix2[HW + pix]; g[5] = b.dL_dpix2[2 * HW + pix]; }
 			}
+			const float bg_dot = p.bg[0] * g[0] + p.bg[1] * g[1] + p.bg[2] * g[2];
+			float bg_dot_b = 0.f;
+			if constexpr (NCH == 6) bg_dot_b = p.bg[0] * g[3] + p.bg[1] * g[4] + p.bg[2] * g[5];
+			FrBwdPixT<NCH> st;
+			fr_bwd_state_load(sg.summ + cid * (FR_BWD_MAP_FLOATS(NCH) * 64) + lane, st);          // the state in front of the chunk (k_backward_sq_prefix)
 			uint32_t my_id, my_pos;
 			{ const uint2 qe = sg.list[cid * 64 + lane]; my_id = qe.x; my_pos = qe.y; }          // (lanes beyond the chunk's candidates: {0, 0}, parked but never read)
 			const float4 q0 = splat[2 * (size_t)my_id], q1 = splat[2 * (size_t)my_id + 1];      // {x, y, conx, cony} {conz, opacity, depth, ext}
@@ -6174,6 +6243,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 					ent[e][0] = q0;
 					ent[e][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(my_pos));
 					ent[e][2] = make_float4(b.colors[3 * (size_t)my_id], b.colors[3 * (size_t)my_id + 1], b.colors[3 * (size_t)my_id + 2], 0.f);
+					if constexpr (NCH == 6) ent[e][3] = make_float4(b.colors2[3 * (size_t)my_id], b.colors2[3 * (size_t)my_id + 1], b.colors2[3 * (size_t)my_id + 2], 0.f);
 				}
 				if constexpr (POW == 2)
 				{
@@ -6198,6 +6268,9 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 					const bool ok = ((mask >> jj) & 1ull) != 0ull && fr_sq_test(r0, r1, pfx, pfy, ncontrib, dx, dy, G, alpha);
 					if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
 					const float cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
+					float rc[NCH];
+					rc[0] = r2.x; rc[1] = r2.y; rc[2] = r2.z;
+					if constexpr (NCH == 6) { const float4 r3 = ent[j][3]; rc[3] = r3.x; rc[4] = r3.y; rc[5] = r3.z; }
 					float tot;
 					if constexpr (POW == 2)
 					{
@@ -6205,7 +6278,8 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 						if (ok)
 						{
 							// backward.cu:978-1038
-							float da = fr_sq_update(st, alpha, r2, g);
+							float da, db;
+							fr_bwd_update(st, alpha, rc, g, da, db);
 							wcol = alpha * st.Tc;
 							if (bg_dot != 0.f) da += (-T_final / (1.f - alpha)) * bg_dot;
 							w = (o * da) * G;                                              // dL_dG * G
@@ -6254,23 +6328,29 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 					else
 					{
 						// backward.cu:978-1038: the terms of k_backward_lin_walk, zero on a lane without the pair
-						float dL_dalpha = 0.f, wcol = 0.f;
+						float da = 0.f, db = 0.f, wcol = 0.f;
 						if (ok)
 						{
-							dL_dalpha = fr_sq_update(st, alpha, r2, g);
+							fr_bwd_update(st, alpha, rc, g, da, db);
 							wcol = alpha * st.Tc;
-							if (bg_dot != 0.f) dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+							const float bgf = -T_final / (1.f - alpha);
+							if (bg_dot != 0.f) da += bgf * bg_dot;
+							if (NCH == 6 && bg_dot_b != 0.f) db += bgf * bg_dot_b;
 						}
+						const float dL_dalpha = da + db;
 						const float dL_dG = o * dL_dalpha;
 						const float gdx = G * dx, gdy = G * dy;
 						const float dG_ddelx = -gdx * cx - gdy * cy, dG_ddely = -gdy * cz - gdx * cy;
+						const float oa = NCH == 6 ? o * da : dL_dG;                   // screen-space gradient of the first image (of the only one)
 						float v[16];
-						v[0] = dL_dG * dG_ddelx * hw; v[1] = dL_dG * dG_ddely * hh;
+						v[0] = oa * dG_ddelx * hw; v[1] = oa * dG_ddely * hh;
 						v[2] = -0.5f * gdx * dx * dL_dG; v[3] = -0.5f * gdx * dy * dL_dG; v[4] = -0.5f * gdy * dy * dL_dG;
-						v[5] = wcol * g[0]; v[6] = wcol * g[1]; v[7] = wcol * g[2];
-						v[8] = G * dL_dalpha;
 #pragma unroll
-						for (int k = 9; k < 16; k++) v[k] = 0.f;
+						for (int c = 0; c < NCH; c++) v[5 + c] = wcol * g[c];
+						v[5 + NCH] = G * dL_dalpha;
+						if constexpr (NCH == 6) { const float ob = o * db; v[12] = ob * dG_ddelx * hw; v[13] = ob * dG_ddely * hh; }
+#pragma unroll
+						for (int k = (NCH == 6 ? 14 : 9); k < 16; k++) v[k] = 0.f;
 						tot = fr_reduce_scatter16(v, lane);
 					}
 					const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, jj);
@@ -6875,7 +6955,7 @@ extern "C" int fr_forward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 #define FR_SQ_SEG_MAX_TILES 16384    // (2048 x 2048; the chunked form wins at every size measured: 2.0-3.9x from 128 x 128 to 1200 x 680, tools/backward_p2_bench.py)
 #define FR_SQ_MAX_SCRATCH (4ull << 30)
 struct FrSqScratch { size_t slot_map, ctl, cnt, work, ctodo, list, pixmask, summ, bytes; uint32_t n_slots, n_chunks; };
-static FrSqScratch fr_sq_scratch(int64_t T, int64_t R)
+static FrSqScratch fr_sq_scratch(int64_t T, int64_t R, int nch = 3)
 {
 	FrSqScratch q;
 	const uint32_t L = fr_sq_seg_length_of((uint32_t)(R > 0 ? R : 1), (uint32_t)T);
@@ -6889,7 +6969,7 @@ static FrSqScratch fr_sq_scratch(int64_t T, int64_t R)
 	q.ctodo = o; o = fr_align(o + (size_t)q.n_chunks * sizeof(uint2));
 	q.pixmask = o; o = fr_align(o + (size_t)q.n_chunks * 64 * sizeof(uint2));
 	q.list = o; o = fr_align(o + (size_t)q.n_chunks * 64 * sizeof(uint2));
-	q.summ = o; o = fr_align(o + (size_t)q.n_chunks * 9 * 64 * sizeof(float));
+	q.summ = o; o = fr_align(o + (size_t)q.n_chunks * FR_BWD_MAP_FLOATS(nch) * 64 * sizeof(float));
 	q.bytes = o;
 	return q;
 }
@@ -6900,6 +6980,45 @@ extern "C" size_t fr_backward_scratch_bytes(int32_t P, int32_t W, int32_t H, int
 	if (T > FR_SQ_SEG_MAX_TILES) return 0;
 	const size_t bytes = fr_sq_scratch(T, num_rendered).bytes;
 	return bytes <= FR_SQ_MAX_SCRATCH ? bytes : 0;
+}
+extern "C" size_t fr_backward_pair_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t num_rendered)
+{
+	if (P <= 0 || W <= 0 || H <= 0 || num_rendered <= 0 || num_rendered > 0x7fffffffll) return 0;
+	const int64_t T = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
+	if (T > FR_SQ_SEG_MAX_TILES) return 0;
+	const size_t bytes = fr_sq_scratch(T, num_rendered, 6).bytes;
+	return bytes <= FR_SQ_MAX_SCRATCH ? bytes : 0;
+}
+
+// The chunked backward (k_backward_sq_slots ... _leaves) on one view; rows: the leaf rows of power 2, null for power 1.  The kernels
+// size their segments from status[0]; num_rendered must be that number: the scratch layout (sq) depends on it.
+template <int NCH>
+static int fr_launch_chunked(const FrParams& p, const FrBwdArgs& b, const FrSqScratch& sq, void* scratch, const float* rows, hipStream_t s)
+{
+	FrSqSegArgs sg;
+	char* sc = (char*)scratch;
+	sg.slot_map = (uint32_t*)(sc + sq.slot_map); sg.ctl = (uint32_t*)(sc + sq.ctl); sg.cnt = (uint32_t*)(sc + sq.cnt);
+	sg.work = (uint2*)(sc + sq.work); sg.ctodo = (uint2*)(sc + sq.ctodo); sg.pixmask = (uint2*)(sc + sq.pixmask);
+	sg.list = (uint2*)(sc + sq.list); sg.summ = (float*)(sc + sq.summ);
+	sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks;
+	const dim3 block(FR_THREADS);
+	int rc;
+	hipLaunchKernelGGL(k_backward_sq_slots, dim3(p.T), block, 0, s, p, b, sg);
+	if ((rc = fr_check_launch("k_backward_sq_slots"))) return rc;
+	hipLaunchKernelGGL((k_backward_sq_chunks<NCH>), dim3(sg.n_slots), block, 0, s, p, b, sg);
+	if ((rc = fr_check_launch("k_backward_sq_chunks"))) return rc;
+	hipLaunchKernelGGL((k_backward_sq_prefix<NCH>), dim3(p.T), block, 0, s, p, b, sg);
+	if ((rc = fr_check_launch("k_backward_sq_prefix"))) return rc;
+	// power 2: four workgroups per CU (34 KiB of LDS each; 512 / 768 workgroups: 230 / 205 us against 190 on the benchmark room)
+	const unsigned cap = rows ? 1024u : 2048u;
+	const unsigned grid = sg.n_chunks / 4u + 1u < cap ? sg.n_chunks / 4u + 1u : cap;
+	if constexpr (NCH == 3)
+	{
+		if (rows) hipLaunchKernelGGL((k_backward_sq_leaves<2, 3>), dim3(grid), block, 0, s, p, b, rows, sg);
+		else hipLaunchKernelGGL((k_backward_sq_leaves<1, 3>), dim3(grid), block, 0, s, p, b, rows, sg);
+	}
+	else hipLaunchKernelGGL((k_backward_sq_leaves<1, NCH>), dim3(grid), block, 0, s, p, b, rows, sg);
+	return fr_check_launch("k_backward_sq_leaves");
 }
 
 extern "C" int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
@@ -6965,29 +7084,6 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 	b.only_flagged = nullptr;
 	b.u_only = 0;
 	b.dL_dmean2D_b = nullptr;
-	// the chunked form (k_backward_sq_slots ... _leaves); the kernels size their segments from status[0], num_rendered must be that
-	// number: the scratch layout depends on it
-	auto launch_chunked = [&](const float* rows) -> int {
-		FrSqSegArgs sg;
-		char* sc = (char*)scratch;
-		sg.slot_map = (uint32_t*)(sc + sq.slot_map); sg.ctl = (uint32_t*)(sc + sq.ctl); sg.cnt = (uint32_t*)(sc + sq.cnt);
-		sg.work = (uint2*)(sc + sq.work); sg.ctodo = (uint2*)(sc + sq.ctodo); sg.pixmask = (uint2*)(sc + sq.pixmask);
-		sg.list = (uint2*)(sc + sq.list); sg.summ = (float*)(sc + sq.summ);
-		sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks;
-		int rc2;
-		hipLaunchKernelGGL(k_backward_sq_slots, dim3(p.T), block, 0, s, p, b, sg);
-		if ((rc2 = fr_check_launch("k_backward_sq_slots"))) return rc2;
-		hipLaunchKernelGGL(k_backward_sq_chunks, dim3(sg.n_slots), block, 0, s, p, b, sg);
-		if ((rc2 = fr_check_launch("k_backward_sq_chunks"))) return rc2;
-		hipLaunchKernelGGL(k_backward_sq_prefix, dim3(p.T), block, 0, s, p, b, sg);
-		if ((rc2 = fr_check_launch("k_backward_sq_prefix"))) return rc2;
-		// power 2: four workgroups per CU (34 KiB of LDS each; 512 / 768 workgroups: 230 / 205 us against 190 on the benchmark room)
-		const unsigned cap = rows ? 1024u : 2048u;
-		const unsigned grid = sg.n_chunks / 4u + 1u < cap ? sg.n_chunks / 4u + 1u : cap;
-		if (rows) hipLaunchKernelGGL((k_backward_sq_leaves<2>), dim3(grid), block, 0, s, p, b, rows, sg);
-		else hipLaunchKernelGGL((k_backward_sq_leaves<1>), dim3(grid), block, 0, s, p, b, rows, sg);
-		return fr_check_launch("k_backward_sq_leaves");
-	};
 	if (power == 1)
 	{
 		// gradients: sum u per splat in the tile kernel, Jacobian chain once per Gaussian; tiles that do not fit the LDS
@@ -7012,7 +7108,7 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 #endif
 		if (segmented)
 		{
-			if ((rc = launch_chunked(nullptr))) return rc;
+			if ((rc = fr_launch_chunked<3>(p, b, sq, scratch, nullptr, s))) return rc;
 			b.u_only = 1;
 		}
 		else
@@ -7036,7 +7132,7 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 		float* rows = (float*)((char*)geom_ws + L.packed);           // [P][56] floats of the geometry buffer's 256-byte-per-Gaussian region
 		hipLaunchKernelGGL(k_backward_sq_rows, dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, rows);
 		if ((rc = fr_check_launch("k_backward_sq_rows"))) return rc;
-		if (segmented) return launch_chunked((const float*)rows);
+		if (segmented) return fr_launch_chunked<3>(p, b, sq, scratch, (const float*)rows, s);
 		hipLaunchKernelGGL(k_backward_sq_walk, dim3(p.T), block, 0, s, p, b, (const float*)rows);
 		return fr_check_launch("k_backward_sq_walk");
 	}
@@ -7118,6 +7214,19 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
                                 float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
                                 float* dL_drotations, float* dL_dconic, fr_stream_t stream)
 {
+	return fr_backward_pair_ws(cfg, g, radii, geom_ws, binning_ws, image_ws, dL_dout_color, features, dL_dout_features, dL_dmeans2D,
+	                           dL_dmeans2D_features, dL_dcolors, dL_dfeatures, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drotations,
+	                           dL_dconic, 0, nullptr, 0, stream);
+}
+
+extern "C" int fr_backward_pair_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                                   const void* geom_ws, const void* binning_ws, const void* image_ws,
+                                   const float* dL_dout_color, const float* features, const float* dL_dout_features,
+                                   float* dL_dmeans2D, float* dL_dmeans2D_features, float* dL_dcolors, float* dL_dfeatures,
+                                   float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                                   float* dL_drotations, float* dL_dconic,
+                                   int64_t num_rendered, void* scratch, size_t scratch_bytes, fr_stream_t stream)
+{
 	int rc = fr_validate(cfg, g, "fr_backward_pair", false);
 	if (rc) return rc;
 	hipStream_t s = (hipStream_t)stream;
@@ -7128,12 +7237,18 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	    !dL_dmeans2D_features || !dL_dcolors || !dL_dfeatures || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
 	    !dL_drotations || !dL_dconic)
 		return fr_fail(FR_EINVAL, "fr_backward_pair: null pointer");
+	// with a scratch buffer: the chunked form on six colour channels (FR_DEBUG_MODE=33 in the rig: never)
+	const int64_t T_img = ((int64_t)(W + 15) / 16) * ((int64_t)(H + 15) / 16);
+	const size_t scratch_need = fr_backward_pair_scratch_bytes(P, W, H, num_rendered);
+	const bool chunked = scratch && scratch_need > 0 && scratch_bytes >= scratch_need FR_AB_ONLY(&& fr_debug_mode() != 33 && fr_debug_mode() != 18);
+	const FrSqScratch sq = fr_sq_scratch(T_img, chunked ? num_rendered : 1, 6);
 	{
 		FrZeroer z;
 		z.add(dL_dmeans2D, (size_t)P * 3 * 4); z.add(dL_dmeans2D_features, (size_t)P * 3 * 4); z.add(dL_dcolors, (size_t)P * 3 * 4);
 		z.add(dL_dfeatures, (size_t)P * 3 * 4); z.add(dL_dopacity, (size_t)P * 4); z.add(dL_dmeans3D, (size_t)P * 3 * 4);
 		z.add(dL_dcov3D, (size_t)P * 6 * 4); z.add(dL_dscales, (size_t)P * 3 * 4); z.add(dL_drotations, (size_t)P * 4 * 4);
 		z.add(dL_dconic, (size_t)P * 4 * 4);
+		if (chunked) z.add((char*)scratch + sq.slot_map, sq.cnt - sq.slot_map);       // the slot map and the work list's counters
 		z.launch(s);
 	}
 	FrLayout L = fr_layout(P, W, H, 1, 1);
@@ -7158,7 +7273,12 @@ extern "C" int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g,
 	b.only_flagged = nullptr; b.u_only = 0;
 	// (the pair keeps the two-pass tile kernel: with fourteen accumulators per candidate the walk form measured 0.83 against
 	// 0.79 ms at 2M Gaussians / 512 x 512 -- the single image gains, 0.49 against 0.59; FR_DEBUG_MODE=18 forces the walk form)
-	const bool pair_walk = fr_debug_mode() == 18;
+	const bool pair_walk = fr_debug_mode() == 18 || chunked;
+	if (chunked)
+	{
+		if ((rc = fr_launch_chunked<6>(p, b, sq, scratch, nullptr, s))) return rc;
+	}
+	else
 #ifdef FR_AB
 	if (pair_walk)
 	{

@@ -40,7 +40,7 @@ def rasterize_features(features, raster_cfg_args, geomBuffer, binningBuffer, ima
 
 def rasterize_gaussians_backward_pair(background, means3D, radii, colors, features, scales, rotations, scale_modifier,
                                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                      dL_dout_features, campos, geomBuffer, binningBuffer, imageBuffer):
+                                      dL_dout_features, campos, geomBuffer, binningBuffer, imageBuffer, num_rendered=0):
     return _ops.rasterize_backward_pair(background, means3D, radii, colors, features, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                        dL_dout_features, campos, geomBuffer, binningBuffer, imageBuffer)
+                                        dL_dout_features, campos, geomBuffer, binningBuffer, imageBuffer, num_rendered=num_rendered)

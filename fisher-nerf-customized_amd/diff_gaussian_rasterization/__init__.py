@@ -89,6 +89,7 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
             rs.sh_degree, rs.campos, rs.prefiltered)
         ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii, depth)
         return color, radii, depth, feat_img
@@ -103,7 +104,8 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
             grad_features = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
         (g_m2, g_m2f, g_col, g_feat, g_op, g_m3, g_cov, g_sc, g_rot) = _C.rasterize_gaussians_backward_pair(
             rs.bg, means3D, radii, colors_precomp, features, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_features, rs.campos, geom, binning, img)
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_features, rs.campos, geom, binning, img,
+            num_rendered=ctx.num_rendered)
 
         def fit(g, like):
             return None if (like is None or like.numel() == 0) else g

@@ -84,7 +84,7 @@ class OccCfg(ctypes.Structure):
 # every symbol include/fisher_rast.h and include/fisher_occ.h declare
 EXPORTS = (
     "fr_version", "fr_last_error", "fr_build_id", "fr_init", "fr_fisher_workspace_layout", "fr_workspace_bytes", "fr_workspace_layout", "fr_mark_visible",
-    "fr_forward", "fr_backward", "fr_backward_scratch_bytes", "fr_backward_ws", "fr_forward_pair", "fr_forward_features", "fr_backward_pair", "fr_fisher_workspace_bytes", "fr_fisher_views",
+    "fr_forward", "fr_backward", "fr_backward_scratch_bytes", "fr_backward_ws", "fr_forward_pair", "fr_forward_features", "fr_backward_pair", "fr_backward_pair_scratch_bytes", "fr_backward_pair_ws", "fr_fisher_workspace_bytes", "fr_fisher_views",
     "fr_densify_stats", "fr_densify_masks", "fr_prune_mask", "fr_knn_workspace_bytes", "fr_knn_dist2", "fr_spatial_order_workspace_bytes", "fr_spatial_order", "fr_profile_enable", "fr_profile_fetch",
     "fr_occ_workspace_bytes", "fr_occ_update", "fr_occ_freespace", "fr_occ_frontiers", "fr_occ_erode", "fr_occ_cells_of",
     "fr_occ_ring_candidates", "fr_occ_free_candidates",
@@ -176,6 +176,12 @@ def load():
     lib.fr_backward_pair.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians), ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      _f32p, _f32p, _f32p] + [_f32p] * 10 + [ctypes.c_void_p]
+    lib.fr_backward_pair_scratch_bytes.restype = ctypes.c_size_t
+    lib.fr_backward_pair_scratch_bytes.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_int64]
+    lib.fr_backward_pair_ws.restype = ctypes.c_int
+    lib.fr_backward_pair_ws.argtypes = [ctypes.POINTER(RasterCfg), ctypes.POINTER(Gaussians), ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        _f32p, _f32p, _f32p] + [_f32p] * 10 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.fr_fisher_workspace_bytes.restype = ctypes.c_size_t
     lib.fr_fisher_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int64, ctypes.c_int32]

@@ -232,7 +232,7 @@ def rasterize_forward_features(features, raster_cfg_args, geomBuffer, binningBuf
 
 def rasterize_backward_pair(background, means3D, radii, colors, features, scales, rotations, scale_modifier, cov3D_precomp,
                             viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_features, campos,
-                            geomBuffer, binningBuffer, imageBuffer):
+                            geomBuffer, binningBuffer, imageBuffer, num_rendered=0, segmented=True):
     """Backward of (colour image, feature image) on shared geometry, grad_power 1 (fr_backward_pair): returns
     (dL_dmeans2D [colour image only], dL_dmeans2D_features, dL_dcolors, dL_dfeatures, dL_dopacity, dL_dmeans3D, dL_dcov3D,
      dL_dscales, dL_drotations)."""
@@ -252,11 +252,16 @@ def rasterize_backward_pair(background, means3D, radii, colors, features, scales
     if P != 0:
         cfg = _raster_cfg(P, H, W, tan_fovx, tan_fovy, scale_modifier, 0, 0, False, bg, view, proj, cpos)
         g = _gaussians(means3D, colors, None, None, scales, rotations, cov3D_precomp)
+        lib = _lib.load()
+        # with the forward's num_rendered: scratch for the chunked form (fisher_rast.h, fr_backward_pair_ws)
+        nscr = int(lib.fr_backward_pair_scratch_bytes(P, W, H, int(num_rendered))) if (segmented and num_rendered) else 0
+        scratch = _backward_scratch(dev, nscr) if nscr else None
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().fr_backward_pair(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
-                                                    binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), _ptr(feats), _ptr(dLf),
-                                                    _ptr(m2), _ptr(m2f), _ptr(dc), _ptr(df), _ptr(dop), _ptr(dm3), _ptr(dcov),
-                                                    _ptr(dsc), _ptr(drot), _ptr(dcon), _stream(dev)), "fr_backward_pair")
+            _lib.check(lib.fr_backward_pair_ws(ctypes.byref(cfg), ctypes.byref(g), radii.data_ptr(), geomBuffer.data_ptr(),
+                                               binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL), _ptr(feats), _ptr(dLf),
+                                               _ptr(m2), _ptr(m2f), _ptr(dc), _ptr(df), _ptr(dop), _ptr(dm3), _ptr(dcov),
+                                               _ptr(dsc), _ptr(drot), _ptr(dcon), int(num_rendered), scratch.data_ptr() if nscr else None,
+                                               scratch.numel() if nscr else 0, _stream(dev)), "fr_backward_pair")
     return m2, m2f, dc, df, dop, dm3, dcov, dsc, drot
 
 

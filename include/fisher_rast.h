@@ -133,7 +133,8 @@ int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* 
                 fr_stream_t stream);
 
 /* fr_backward with a scratch buffer the power-2 backward may use: fr_backward_scratch_bytes(P, W, H, power, num_rendered) bytes,
- * num_rendered = what fr_forward reported for this image (status[0]); 0 = no use for one (power 1; more than 16384 tiles or 4 GiB).
+ * num_rendered = what fr_forward reported for this image (status[0]); 0 = no use for one (other powers; more than 16384 tiles or 4 GiB).
+ * (Power 1, the training backward, takes the same scratch and the same route for its nine per-candidate sums.)
  * fr_backward's power-2 pass is one workgroup per tile -- one 256 x 256 view is 256 workgroups on 256 CUs, the longest tile list sets
  * the time of the literal `backward_power=2` loop (models/SLAM/gaussian.py:1548-1549) -- and its per-candidate LDS accumulators
  * serialise under splats that cover a strip; given the scratch, the backward is cut into chunks of at most 64
@@ -171,6 +172,17 @@ int fr_backward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, const int3
                      float* dL_dmeans2D, float* dL_dmeans2D_features, float* dL_dcolors, float* dL_dfeatures,
                      float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
                      float* dL_drotations, float* dL_dconic, fr_stream_t stream);
+
+/* fr_backward_pair with the scratch buffer of the chunked form (fr_backward_ws, above; six colour channels in the per-chunk state):
+ * fr_backward_pair_scratch_bytes(P, W, H, num_rendered) bytes, num_rendered = what the forward of this image reported. */
+size_t fr_backward_pair_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t num_rendered);
+int fr_backward_pair_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
+                        const void* geom_ws, const void* binning_ws, const void* image_ws,
+                        const float* dL_dout_color, const float* features, const float* dL_dout_features,
+                        float* dL_dmeans2D, float* dL_dmeans2D_features, float* dL_dcolors, float* dL_dfeatures,
+                        float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                        float* dL_drotations, float* dL_dconic,
+                        int64_t num_rendered, void* scratch, size_t scratch_bytes, fr_stream_t stream);
 
 /* ---- fused multi-view Fisher scorer -------------------------------------------------------------- */
 

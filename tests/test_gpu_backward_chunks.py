@@ -86,3 +86,32 @@ def test_chunks_against_the_oracle(gpu, oracle):
         tol = 1e-4 * np.abs(o) + 1e-6 * np.abs(o).max()
         bad = np.abs(g - o) > tol
         assert not bad.any(), (n, int(bad.sum()), float((np.abs(g - o) / np.maximum(tol, 1e-300)).max()))
+
+
+@pytest.mark.parametrize("P,W,H,bg", [(200_000, 256, 256, 0.0), (120_000, 250, 130, 0.7)])
+def test_pair_chunks_match_the_tile_kernel(gpu, oracle, P, W, H, bg):
+    """fr_backward_pair_ws (colour image + a second feature image, six channels in the chunk maps) against fr_backward_pair's two-pass tile
+    kernel on the same forward: every output within 1e-4 of the entry plus a sliver of the tensor's scale (signed sums)."""
+    from fisher_rast import ops
+    from fisher_rast.synthetic import intrinsics
+    sc = _room(P, W, H, 7)
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), np.eye(4, dtype=np.float32))._replace(bg=np.full(3, bg, np.float32))
+    fwd = hip_forward(gpu, cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    assert int(fwd["tile_count"].max()) > 2 * 256
+    rng = np.random.default_rng(11)
+    feats = to_dev(rng.uniform(0, 1, (P, 3)).astype(np.float32), gpu)
+    dLa, dLb = to_dev(rng.normal(size=(3, H, W)).astype(np.float32), gpu), to_dev(rng.normal(size=(3, H, W)).astype(np.float32), gpu)
+    t = fwd["tensors"]
+    geom, binning, img = fwd["buffers"]
+    out = {}
+    for seg in (True, False):
+        o = ops.rasterize_backward_pair(t["bg"], t["means3D"], fwd["radii_t"], t["colors"], feats, t["scales"], t["rotations"], cam.scale_modifier,
+                                        t["cov3D"], t["view"], t["proj"], cam.tanfovx, cam.tanfovy, dLa, dLb, t["campos"], geom, binning, img,
+                                        num_rendered=fwd["num_rendered"], segmented=seg)
+        torch.cuda.synchronize()
+        out[seg] = [x.cpu().numpy().astype(np.float64) for x in o]
+    names = ("means2D", "means2D_features", "colors", "features", "opacity", "means3D", "cov3D", "scales", "rotations")
+    for n, a, b in zip(names, out[True], out[False]):
+        assert np.abs(b).max() > 0, n
+        tol = 1e-4 * np.abs(b) + 2e-5 * np.abs(b).max()
+        assert (np.abs(a - b) <= tol).all(), (n, float((np.abs(a - b) / tol).max()))

@@ -60,7 +60,7 @@ def fused_pair():
                                                                          cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, H, W, e, 0, cam.campos, False,
                                                                          features=feats)
     return ops.rasterize_backward_pair(cam.bg, tp, radii, act["rgb_colors"], feats, act["scales"], act["rotations"], 1.0, e, cam.viewmatrix,
-                                       cam.projmatrix, cam.tanfovx, cam.tanfovy, dL, dL2, cam.campos, geom, binning, img)
+                                       cam.projmatrix, cam.tanfovx, cam.tanfovy, dL, dL2, cam.campos, geom, binning, img, num_rendered=R)
 
 
 for name, fn in (("two renders (reference flow)", two_renders), ("fused pair", fused_pair)):
