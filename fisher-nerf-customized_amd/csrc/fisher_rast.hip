@@ -1130,6 +1130,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				constexpr int PSB = FrPackSize<C>::value;
 				const float4* pk = (const float4*)(ra.packed + (size_t)i * PSB);
 				const float4 t0 = pk[0], t1 = pk[1], t2 = pk[2];
+				// (the opacity with them: loaded behind the projection, for the visible ones only, it was a load nothing overlapped)
+				const float o_pre = p.opac[p.order ? p.order[i] : (uint32_t)i];
 				const fr_f3 pw = fr_f3{ t0.x, t0.y, t0.z };
 				float c3[6];
 				c3[0] = t0.w; c3[1] = t1.x; c3[2] = t1.y; c3[3] = t1.z; c3[4] = t1.w; c3[5] = t2.x;
@@ -1142,7 +1144,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_preprocess_views_c(FrParams p, F
 				}
 				const fr_f3 po = has_w2c ? fr_world_to_cam(pw, wm) : pw;
 				sp = fr_preprocess_one(po, c3, vm, pm, p.W, p.H, p.tanfovx, p.tanfovy, p.focal_x, p.focal_y, p.gx, p.gy);
-				if (sp.radius > 0) { o = p.opac[p.order ? p.order[i] : (uint32_t)i]; ext = fr_alpha_extent(sp.conx, sp.cony, sp.conz, o); }
+				if (sp.radius > 0) { o = o_pre; ext = fr_alpha_extent(sp.conx, sp.cony, sp.conz, o); }
 			}
 			const bool vis = sp.radius > 0;
 			// ---- ordered ranks.  The pending list is a sequence of rounds, each sorted by (view, index), so the pairs of one view stand
