@@ -4243,6 +4243,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 	if (64u + lane < n) id2 = (uint32_t)gk[64 + lane];
 	uint32_t base = 0;
 	bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+#ifdef FR_FWD_STATS
+	long long st_t0 = (long long)__builtin_amdgcn_s_memtime(), st_stream = 0, st_setup = 0, st_walk = 0;
+	uint32_t st_chunks = 0, st_steps = 0, st_windows = 0;
+#define FR_FWD_STAMP(acc) { const long long t = (long long)__builtin_amdgcn_s_memtime(); acc += t - st_t0; st_t0 = t; }
+#else
+#define FR_FWD_STAMP(acc)
+#endif
 	while (!all_done)
 	{
 		// ---- stream: fill the ring up to one chunk
@@ -4261,7 +4268,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 			if (ov) wq[(qh + qn + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (FR_QCAP - 1)] = make_uint2(idc, base + (uint32_t)lane);
 			qn += (uint32_t)__popcll(om);
 			base += 64;
+#ifdef FR_FWD_STATS
+			st_windows++;
+#endif
 		}
+		FR_FWD_STAMP(st_stream)
 		if (qn == 0) break;
 		// ---- chunk: up to 64 candidates, one per lane
 		const uint32_t m = qn < 64u ? qn : 64u;
@@ -4287,6 +4298,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 		if (done) mask = 0ull;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		FR_FWD_STAMP(st_setup)
+#ifdef FR_FWD_STATS
+		st_chunks++;
+		{ uint32_t pc = (uint32_t)__popcll(mask); for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)pc, o, 64); pc = t > pc ? t : pc; } st_steps += pc; }
+#endif
 		// ---- walk
 		while (mask != 0ull)
 		{
@@ -4313,7 +4329,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_render_forward_walk(FrParams p, 
 			last_contributor = __float_as_uint(r2.w) + 1u;
 		}
 		all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+		FR_FWD_STAMP(st_walk)
 	}
+#ifdef FR_FWD_STATS
+	if (out_depth && inside && lane < 8)
+	{
+		// (rig: the wave's counters in place of the depth of its first eight pixels -- tools/fwd_walk_stats.py)
+		const float vals[8] = { (float)(st_stream >> 6), (float)(st_setup >> 6), (float)(st_walk >> 6), (float)st_chunks, (float)st_steps, (float)st_windows, (float)n, 0.f };
+		D = vals[lane];
+	}
+#endif
 	if (inside)
 	{
 		const size_t HW = (size_t)p.H * p.W;
