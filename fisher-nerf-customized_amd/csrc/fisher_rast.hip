@@ -5649,7 +5649,7 @@ __device__ __forceinline__ void fr_bwd_update(FrBwdPixT<NCH>& st, float alpha, c
 // on the state (backward.cu:951-975), so the contributor sets are the single pass's.
 struct FrSqSegArgs {
 	uint32_t* slot_map;   // [n_slots] tile + 1, or 0
-	uint32_t* ctl;        // [0] full chunks listed, [1] last (partial) chunks listed
+	uint32_t* ctl;        // [0] full chunks listed, [1] last (partial) chunks listed, [2] set when the caller's num_rendered is below status[0]
 	uint2* work;          // [2][n_chunks] the work list {chunk, tile << 2 | strip}: full chunks (64 candidates), then the last chunk of every (segment, strip)
 	uint2* pixmask;       // [n_chunks][64] per pixel-lane: which of the chunk's candidates may touch it (as 2 x u32)
 	uint2* ctodo;         // [n_chunks] which candidates touch any pixel of the strip
@@ -5657,6 +5657,7 @@ struct FrSqSegArgs {
 	uint2* list;          // [n_chunks][64] {Gaussian, position in the tile's list}
 	float* summ;          // [n_chunks][9][64] the chunk's map; k_backward_sq_prefix overwrites rows 0-7 with the state in front of the chunk
 	uint32_t n_slots, n_chunks;
+	uint32_t num_rendered;     // what the caller said fr_forward reported: the scratch is laid out for it
 };
 __host__ __device__ __forceinline__ uint32_t fr_sq_seg_length_of(uint32_t R, uint32_t T)
 {
@@ -5676,6 +5677,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_slots(FrParams p, Fr
 	const uint32_t pxx = tx * FR_BLOCK_X + (tid & 15), pxy = ty * FR_BLOCK_Y + (tid >> 4);
 	const bool inside = pxx < (uint32_t)p.W && pxy < (uint32_t)p.H;
 	if (tid == 0) s_nmax = 0u;
+	// a scratch laid out for fewer tile instances than there are: every kernel of the chain leaves (all gradients stay zero --
+	// plainly wrong rather than partly right)
+	if ((uint32_t)p.status[0] > sg.num_rendered) { if (tid == 0 && blockIdx.x == 0) sg.ctl[2] = 1u; return; }
 	__syncthreads();
 	uint32_t nmax = inside ? b.n_contrib[(size_t)p.W * pxy + pxx] : 0u;
 #pragma unroll
@@ -5767,7 +5771,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 	__shared__ uint2 s_q[4][FR_QCAP];
 	constexpr int EF4 = NCH == 6 ? 4 : 3;
 	__shared__ float4 s_ent[4][64][EF4];
-	if (p.status[1]) return;
+	if (p.status[1] || (uint32_t)p.status[0] > sg.num_rendered) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t slot = blockIdx.x;
@@ -5891,7 +5895,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_chunks(FrParams p, F
 template <int NCH>
 __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_prefix(FrParams p, FrBwdArgs b, FrSqSegArgs sg)
 {
-	if (p.status[1]) return;
+	if (p.status[1] || (uint32_t)p.status[0] > sg.num_rendered) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t tile = blockIdx.x;
@@ -6186,7 +6190,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 	constexpr int NR4 = FR_SQ_ROWS / 4, EF4 = NCH == 6 ? 4 : 3;
 	__shared__ float4 s_ent[4][32][EF4];            // half a chunk at a time: 34 KiB per workgroup, four workgroups per CU
 	__shared__ float4 s_rows[4][POW == 2 ? NR4 : 1][32];      // the leaf rows, [float4 of the row block][candidate]: written by LDS-direct loads
-	if (p.status[1]) return;
+	if (p.status[1] || (uint32_t)p.status[0] > sg.num_rendered) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const float4* splat = (const float4*)p.splat;
@@ -6981,11 +6985,12 @@ extern "C" int fr_forward_pair(const fr_raster_cfg* cfg, const fr_gaussians* g, 
 // slots per (segment, strip); per chunk slot its candidate list (512 B) and nine floats per pixel-lane (2304 B).
 #define FR_SQ_SEG_MAX_TILES 16384    // (2048 x 2048; the chunked form wins at every size measured: 2.0-3.9x from 128 x 128 to 1200 x 680, tools/backward_p2_bench.py)
 #define FR_SQ_MAX_SCRATCH (4ull << 30)
-struct FrSqScratch { size_t slot_map, ctl, cnt, work, ctodo, list, pixmask, summ, bytes; uint32_t n_slots, n_chunks; };
+struct FrSqScratch { size_t slot_map, ctl, cnt, work, ctodo, list, pixmask, summ, bytes; uint32_t n_slots, n_chunks, num_rendered; };
 static FrSqScratch fr_sq_scratch(int64_t T, int64_t R, int nch = 3)
 {
 	FrSqScratch q;
 	const uint32_t L = fr_sq_seg_length_of((uint32_t)(R > 0 ? R : 1), (uint32_t)T);
+	q.num_rendered = (uint32_t)(R > 0 ? R : 1);
 	q.n_slots = (uint32_t)((R > 0 ? R : 1) / L + T + 2);
 	q.n_chunks = q.n_slots * 4u * (L / 64u);
 	size_t o = 0;
@@ -7027,7 +7032,7 @@ static int fr_launch_chunked(const FrParams& p, const FrBwdArgs& b, const FrSqSc
 	sg.slot_map = (uint32_t*)(sc + sq.slot_map); sg.ctl = (uint32_t*)(sc + sq.ctl); sg.cnt = (uint32_t*)(sc + sq.cnt);
 	sg.work = (uint2*)(sc + sq.work); sg.ctodo = (uint2*)(sc + sq.ctodo); sg.pixmask = (uint2*)(sc + sq.pixmask);
 	sg.list = (uint2*)(sc + sq.list); sg.summ = (float*)(sc + sq.summ);
-	sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks;
+	sg.n_slots = sq.n_slots; sg.n_chunks = sq.n_chunks; sg.num_rendered = sq.num_rendered;
 	const dim3 block(FR_THREADS);
 	int rc;
 	hipLaunchKernelGGL(k_backward_sq_slots, dim3(p.T), block, 0, s, p, b, sg);

@@ -140,7 +140,9 @@ int fr_backward(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* 
  * serialise under splats that cover a strip; given the scratch, the backward is cut into chunks of at most 64
  * candidates of one 16 x 4 pixel strip that run as independent pieces of work (a cheap pass leaves each chunk's effect on a pixel's
  * back-to-front state, a prefix pass the state in front of every chunk).  The same pairs contribute; a pixel's state at the start of a
- * chunk differs from the single pass's by rounding only (a few 1e-7 relative).  scratch == NULL or too small: fr_backward's single pass. */
+ * chunk differs from the single pass's by rounding only (a few 1e-7 relative).  scratch == NULL or too small: fr_backward's single pass.
+ * num_rendered below what the forward reported (a scratch laid out for too few tile instances): the kernels notice and leave every
+ * gradient zero. */
 size_t fr_backward_scratch_bytes(int32_t P, int32_t W, int32_t H, int32_t power, int64_t num_rendered);
 int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, const int32_t* radii,
                    const void* geom_ws, const void* binning_ws, const void* image_ws,

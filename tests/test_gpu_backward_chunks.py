@@ -115,3 +115,23 @@ def test_pair_chunks_match_the_tile_kernel(gpu, oracle, P, W, H, bg):
         assert np.abs(b).max() > 0, n
         tol = 1e-4 * np.abs(b) + 2e-5 * np.abs(b).max()
         assert (np.abs(a - b) <= tol).all(), (n, float((np.abs(a - b) / tol).max()))
+
+
+def test_a_scratch_laid_out_for_too_few_instances_gives_zero_gradients(gpu, oracle):
+    """fr_backward_ws with num_rendered below what the forward reported: the chunk kernels notice (status[0] on the device) and leave the
+    gradients zero instead of writing past the slots the scratch has."""
+    import ctypes
+    from fisher_rast import ops, _lib
+    from fisher_rast.synthetic import intrinsics
+    P, W, H = 60_000, 128, 96
+    sc = _room(P, W, H, 2)
+    cam = oracle.setup_camera(W, H, intrinsics(W, H), np.eye(4, dtype=np.float32))
+    fwd = hip_forward(gpu, cam, sc["means3D"], sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+    t = fwd["tensors"]
+    geom, binning, img = fwd["buffers"]
+    dL = to_dev(np.full((3, H, W), 1e-3, np.float32), gpu)
+    for claimed, expect_zero in ((fwd["num_rendered"] // 4, True), (fwd["num_rendered"], False)):
+        o = ops.rasterize_backward(t["bg"], t["means3D"], fwd["radii_t"], t["colors"], t["scales"], t["rotations"], cam.scale_modifier, t["cov3D"], t["view"],
+                                   t["proj"], cam.tanfovx, cam.tanfovy, dL, t["sh"], cam.sh_degree, t["campos"], geom, claimed, binning, img, 2)
+        torch.cuda.synchronize()
+        assert bool((o[3] == 0).all()) == expect_zero
