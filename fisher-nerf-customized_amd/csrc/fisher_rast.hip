@@ -5533,6 +5533,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_lin_walk(FrParams p, Fr
 // built and dropped: a row that is nearly orthogonal to a needle's u-distribution cancels in the quadratic form, 4 of 60 000
 // entries of the `general` test family missed 1e-4 by a factor of 12.)
 #define FR_SQ_ROWS 56                // floats per Gaussian: mean rows 3 x 5, cov3D rows 6 x 3, scale / rotation rows 7 x 3, 1 / opacity^2, pad
+#define FR_SQ_ROW_STRIDE 64          // ... at 256-byte steps: a candidate's 224 bytes are two 128-byte lines, never three
 #define FR_SQ_NL 25                  // leaves: mean2D 2, conic 3, colour 3, opacity 1, mean3D 3, cov3D 6, scale 3, rotation 4
 __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_rows(FrParams p, float* __restrict__ rows)
 {
@@ -5565,7 +5566,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_rows(FrParams p, flo
 		for (int c = 0; c < 3; c++) r[33 + a * 3 + c] = Cg[a][c];
 	const float o = ((const float4*)p.splat)[2 * (size_t)i + 1].y;      // the forward's record {conz, opacity, depth, ext}: the backward ABI carries no opacities
 	r[54] = 1.0f / (o * o); r[55] = 0.f;
-	float4* dst = (float4*)(rows + (size_t)i * FR_SQ_ROWS);
+	float4* dst = (float4*)(rows + (size_t)i * FR_SQ_ROW_STRIDE);
 #pragma unroll
 	for (int k = 0; k < FR_SQ_ROWS / 4; k++) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
 }
@@ -6023,7 +6024,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_backward_sq_walk(FrParams p, FrB
 			ent[lane][0] = q0;
 			ent[lane][1] = make_float4(q1.x, q1.y, fr_power_threshold(q1.y), __uint_as_float(qe.y));
 			ent[lane][2] = make_float4(b.colors[3 * (size_t)my_id], b.colors[3 * (size_t)my_id + 1], b.colors[3 * (size_t)my_id + 2], 0.f);
-			const float4* rsrc = (const float4*)(rows + (size_t)my_id * FR_SQ_ROWS);
+			const float4* rsrc = (const float4*)(rows + (size_t)my_id * FR_SQ_ROW_STRIDE);
 #pragma unroll
 			for (int k = 0; k < FR_SQ_ROWS / 4; k++) ent[lane][3 + k] = rsrc[k];
 			const float4 a = make_float4(q0.x, q0.y, q1.w, __builtin_amdgcn_logf(q1.y));
@@ -6282,7 +6283,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void k_backward_sq_leaves(FrParams p
 					// compiler waits for each of the fourteen loads in turn): one instruction moves float4 2 kk of the 32 candidates on lanes
 					// 0-31 and float4 2 kk + 1 on lanes 32-63 -- the lane-linear image the LDS-direct load writes is exactly rws[2 kk .. 2 kk + 1][.]
 					const uint32_t cand_id = (uint32_t)__shfl((int)my_id, (lane & 31) + 32 * h, 64);     // (a candidate beyond m: Gaussian 0's rows, never read)
-					const float4* rsrc = (const float4*)(rows + (size_t)cand_id * FR_SQ_ROWS) + (lane >> 5);
+					const float4* rsrc = (const float4*)(rows + (size_t)cand_id * FR_SQ_ROW_STRIDE) + (lane >> 5);
 #pragma unroll
 					for (int kk = 0; kk < NR4 / 2; kk++) __builtin_amdgcn_global_load_lds(rsrc + 2 * kk, &rws[2 * kk][0], 16, 0, 0);
 					__builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
@@ -7161,7 +7162,7 @@ extern "C" int fr_backward_ws(const fr_raster_cfg* cfg, const fr_gaussians* g, c
 		// The diagonal Fisher proxy as the reference's own loop asks for it (gaussian.py:1536-1556: one view, autograd, power 2):
 		// the leaf rows once per visible Gaussian (k_backward_sq_rows), then the walking tile kernel (k_backward_sq_walk).
 		// FR_DEBUG_MODE=21 keeps round 2's all-leaves tile kernel (k_fisher_tile_v2<25>) for A/B runs.
-		float* rows = (float*)((char*)geom_ws + L.packed);           // [P][56] floats of the geometry buffer's 256-byte-per-Gaussian region
+		float* rows = (float*)((char*)geom_ws + L.packed);           // [P] x 56 floats at 256-byte steps (FR_SQ_ROW_STRIDE) in the geometry buffer's per-Gaussian region
 		hipLaunchKernelGGL(k_backward_sq_rows, dim3((P + FR_THREADS - 1) / FR_THREADS), block, 0, s, p, rows);
 		if ((rc = fr_check_launch("k_backward_sq_rows"))) return rc;
 		if (segmented) return fr_launch_chunked<3>(p, b, sq, scratch, (const float*)rows, s);
